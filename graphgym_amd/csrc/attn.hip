@@ -1,0 +1,208 @@
+// Per-edge attention pieces for the GAT layers (K12-K14): SDDMM scores, softmax
+// over each destination row's entries, and the multi-head weighted aggregation.
+//   dot-product form   gat_id                TfgIDLayer.py:297-355
+//   additive form      GATIDConvLayer        idconv.py:317-332
+//   segment softmax    SparseAdj.softmax     sparse_adj.py:136-151
+// One wavefront owns one destination row: it keeps the row's query in registers,
+// streams the neighbours' keys with coalesced row loads and reduces each head's
+// dot product across its lanes with DPP/permute shuffles.
+#include "common.h"
+
+namespace mp {
+
+__device__ __forceinline__ float wave_sum_seg(float v, int seg_lanes) {
+  // sum within aligned groups of seg_lanes (power of two <= 64) lanes
+  for (int off = seg_lanes >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// s[e*H+h] = scale * <A[row, slice h], B[col, slice h]>
+// Feature columns are walked in tiles of 64; head slices are dh = d / H wide.  When
+// dh is a power of two <= 64 that divides 64 the per-head sums are wave-segment sums.
+__global__ __launch_bounds__(kBlock) void sddmm_dot_kernel(const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col, int64_t N,
+                                                           const float* __restrict__ A, int64_t lda,
+                                                           const float* __restrict__ B, int64_t ldb,
+                                                           int32_t d, int32_t heads, float scale,
+                                                           float* s) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int dh = d / heads;
+  for (int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave; r < N;
+       r += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    for (int e = e0; e < e1; ++e) {
+      const int c = col[e];
+      // general path: each lane accumulates its columns per head, then a full wave sum per head
+      for (int h = 0; h < heads; ++h) {
+        float acc = 0.f;
+        for (int k = lane; k < dh; k += kWave)
+          acc = fmaf(A[r * lda + h * dh + k], B[(int64_t)c * ldb + h * dh + k], acc);
+        acc = wave_sum_seg(acc, kWave);
+        if (lane == 0) s[(int64_t)e * heads + h] = acc * scale;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void sddmm_add_kernel(const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col, int64_t N,
+                                                           const float* __restrict__ ai,
+                                                           const float* __restrict__ aj, float slope,
+                                                           float* s) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave; r < N;
+       r += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    const float a_r = ai[r];
+    for (int e = e0 + lane; e < e1; e += kWave) {
+      const float x = a_r + aj[col[e]];
+      s[e] = x > 0.f ? x : slope * x;  // F.leaky_relu, idconv.py:326
+    }
+  }
+}
+
+// softmax over a row's entries, one wave per (row), heads looped
+__global__ __launch_bounds__(kBlock) void row_softmax_kernel(const int32_t* __restrict__ rowptr, int64_t N,
+                                                             int32_t heads, const float* s, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave; r < N;
+       r += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    for (int h = 0; h < heads; ++h) {
+      float m = -INFINITY;
+      for (int e = e0 + lane; e < e1; e += kWave) m = fmaxf(m, s[(int64_t)e * heads + h]);
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+      float z = 0.f;
+      for (int e = e0 + lane; e < e1; e += kWave) z += expf(s[(int64_t)e * heads + h] - m);
+      z = wave_sum_seg(z, kWave);
+      for (int e = e0 + lane; e < e1; e += kWave)
+        out[(int64_t)e * heads + h] = expf(s[(int64_t)e * heads + h] - m) / z;
+    }
+  }
+}
+
+// ds = p * (dp - sum_row(p * dp))
+__global__ __launch_bounds__(kBlock) void row_softmax_bwd_kernel(const int32_t* __restrict__ rowptr,
+                                                                 int64_t N, int32_t heads,
+                                                                 const float* __restrict__ p,
+                                                                 const float* __restrict__ dp, float* ds) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave; r < N;
+       r += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    for (int h = 0; h < heads; ++h) {
+      float t = 0.f;
+      for (int e = e0 + lane; e < e1; e += kWave)
+        t = fmaf(p[(int64_t)e * heads + h], dp[(int64_t)e * heads + h], t);
+      t = wave_sum_seg(t, kWave);
+      for (int e = e0 + lane; e < e1; e += kWave) {
+        const int64_t i = (int64_t)e * heads + h;
+        ds[i] = p[i] * (dp[i] - t);
+      }
+    }
+  }
+}
+
+// Y[r, c] = sum_e a[e*H + c/dh] * V[col[e], c]
+__global__ __launch_bounds__(kBlock) void spmm_heads_kernel(const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col,
+                                                            const float* __restrict__ a, int64_t N,
+                                                            int32_t heads, const float* __restrict__ V,
+                                                            int64_t ldv, float* Y, int64_t ldy, int32_t d) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int dh = d / heads;
+  for (int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave; r < N;
+       r += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    for (int c = lane; c < d; c += kWave) {
+      const int h = c / dh;
+      float acc = 0.f;
+      for (int e = e0; e < e1; ++e)
+        acc = fmaf(a[(int64_t)e * heads + h], V[(int64_t)col[e] * ldv + c], acc);
+      Y[r * ldy + c] = acc;
+    }
+  }
+}
+
+static int row_grid(int64_t N) {
+  int64_t b = ceil_div(N, kWavesPerBlock);
+  if (b < 1) b = 1;
+  if (b > kNumCU * 16) b = kNumCU * 16;
+  return (int)b;
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+int mp_sddmm_dot_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t nnz, const float* Qm,
+                     int64_t ldq, const float* Km, int64_t ldk, int32_t d, int32_t heads, float scale,
+                     float* s, mp_stream_t stream) {
+  if (!rowptr || N < 0 || nnz < 0 || d <= 0 || heads <= 0 || d % heads) return MP_ERR_INVALID_ARG;
+  if (nnz > 0 && (!col || !Qm || !Km || !s)) return MP_ERR_INVALID_ARG;
+  if (ldq < d || ldk < d) return MP_ERR_INVALID_ARG;
+  if (N == 0 || nnz == 0) return MP_OK;
+  hipLaunchKernelGGL(sddmm_dot_kernel, dim3(row_grid(N)), dim3(kBlock), 0, as_stream(stream), rowptr, col, N,
+                     Qm, ldq, Km, ldk, d, heads, scale, s);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+int mp_sddmm_grad_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t nnz, const float* A,
+                      int64_t lda, const float* B, int64_t ldb, int32_t d, int32_t heads, float* g,
+                      mp_stream_t stream) {
+  return mp_sddmm_dot_f32(rowptr, col, N, nnz, A, lda, B, ldb, d, heads, 1.0f, g, stream);
+}
+
+int mp_sddmm_add_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t nnz, const float* ai,
+                     const float* aj, float slope, float* s, mp_stream_t stream) {
+  if (!rowptr || N < 0 || nnz < 0) return MP_ERR_INVALID_ARG;
+  if (nnz > 0 && (!col || !ai || !aj || !s)) return MP_ERR_INVALID_ARG;
+  if (N == 0 || nnz == 0) return MP_OK;
+  hipLaunchKernelGGL(sddmm_add_kernel, dim3(row_grid(N)), dim3(kBlock), 0, as_stream(stream), rowptr, col, N,
+                     ai, aj, slope, s);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+int mp_csr_row_softmax_f32(const int32_t* rowptr, int64_t N, int32_t heads, const float* s, float* out,
+                           mp_stream_t stream) {
+  if (!rowptr || N < 0 || heads <= 0) return MP_ERR_INVALID_ARG;
+  if (N == 0) return MP_OK;
+  if (!s || !out) return MP_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(row_softmax_kernel, dim3(row_grid(N)), dim3(kBlock), 0, as_stream(stream), rowptr, N,
+                     heads, s, out);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+int mp_csr_row_softmax_bwd_f32(const int32_t* rowptr, int64_t N, int32_t heads, const float* p,
+                               const float* dp, float* ds, mp_stream_t stream) {
+  if (!rowptr || N < 0 || heads <= 0) return MP_ERR_INVALID_ARG;
+  if (N == 0) return MP_OK;
+  if (!p || !dp || !ds) return MP_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3(row_grid(N)), dim3(kBlock), 0, as_stream(stream), rowptr, N,
+                     heads, p, dp, ds);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+int mp_spmm_heads_f32(const int32_t* rowptr, const int32_t* col, const float* a, int64_t N, int32_t heads,
+                      const float* V, int64_t ldv, float* Y, int64_t ldy, int32_t d, mp_stream_t stream) {
+  if (!rowptr || N < 0 || heads <= 0 || d <= 0 || d % heads) return MP_ERR_INVALID_ARG;
+  if (N == 0) return MP_OK;
+  if (!Y || !V || ldv < d || ldy < d) return MP_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(spmm_heads_kernel, dim3(row_grid(N)), dim3(kBlock), 0, as_stream(stream), rowptr, col, a,
+                     N, heads, V, ldv, Y, ldy, d);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// Status strings, error capture, and the host-side synthetic graph generator.
+#include "common.h"
+#include <string>
+#include <vector>
+
+namespace mp {
+static thread_local std::string g_last_hip_error;
+void set_hip_error(hipError_t e, const char* what) {
+  g_last_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+}
+}  // namespace mp
+
+extern "C" {
+
+int mp_version(void) { return 100; }
+
+const char* mp_status_str(int status) {
+  switch (status) {
+    case MP_OK: return "ok";
+    case MP_ERR_INVALID_ARG: return "invalid argument";
+    case MP_ERR_UNSUPPORTED: return "unsupported size (index does not fit int32)";
+    case MP_ERR_WORKSPACE: return "workspace too small";
+    case MP_ERR_HIP: return "HIP runtime error";
+    case MP_ERR_ALIGNMENT: return "misaligned pointer or leading dimension";
+  }
+  return "unknown status";
+}
+
+const char* mp_last_hip_error(void) { return mp::g_last_hip_error.c_str(); }
+
+// Barabasi-Albert by the repeated-endpoints list: a new node t draws m targets
+// uniformly from the list of all edge endpoints so far (probability ∝ degree),
+// then both endpoints of each new edge are appended.  The m seed nodes start
+// with one list entry each so they can be drawn.  Duplicate targets within one
+// node's m draws are kept here; the CSR build of the caller may merge them.
+int mp_gen_ba_edges_host(int64_t n, int32_t m, uint64_t seed, int64_t* u_host, int64_t* v_host,
+                         int64_t* n_edges_host) {
+  if (n <= m || m < 1 || !u_host || !v_host || !n_edges_host) return MP_ERR_INVALID_ARG;
+  if (n >= INT32_MAX) return MP_ERR_UNSUPPORTED;
+  std::vector<int32_t> ends;
+  ends.reserve((size_t)(2 * (int64_t)m * n + m));
+  for (int32_t i = 0; i < m; ++i) ends.push_back(i);
+  uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ull;
+  auto next = [&]() {  // splitmix64
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  int64_t k = 0;
+  for (int64_t t = m; t < n; ++t) {
+    const size_t pool = ends.size();
+    for (int32_t j = 0; j < m; ++j) {
+      // multiply-shift maps a 64-bit draw onto [0, pool)
+      const size_t r = (size_t)(((unsigned __int128)next() * pool) >> 64);
+      const int32_t tgt = ends[r];
+      u_host[k] = t;
+      v_host[k] = tgt;
+      ++k;
+    }
+    for (int32_t j = 0; j < m; ++j) {
+      ends.push_back((int32_t)t);
+      ends.push_back((int32_t)v_host[k - m + j]);
+    }
+  }
+  *n_edges_host = k;
+  return MP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+"""CSRGraph — the device-resident graph format of the engine.
+
+One destination-sorted CSR per (batch, self-loop policy), built once on the GPU
+from the batch's COO ``edge_index`` and cached; the reference instead re-derives
+self-loops, degrees and the GCN normalisation from COO inside every layer call
+(TfgIDLayer.py:500-503,546-558 with cache=None, main_zd.py:69-71;
+idconv.py:165-173 with cached=False).
+
+Row r holds the in-edges of destination r; ``col`` holds source ids.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_hip(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.EngineError(
+            f"{name} must live on a HIP device: the engine has no CPU path "
+            "(the CPU oracle is test infrastructure only)")
+
+
+class CSRGraph:
+    def __init__(self, rowptr, col, val, eid, num_nodes, nnz):
+        self.rowptr = rowptr      # [N+1] int32
+        self.col = col            # [nnz] int32 (view of a capacity-sized buffer)
+        self.val = val            # [nnz] fp32 or None (= ones)
+        self.eid = eid            # [nnz] int32 input position / -1-i for inserted loops, or None
+        self.num_nodes = int(num_nodes)
+        self.nnz = int(nnz)
+        self._plan = None
+        self._t = None            # transpose cache
+        self._t_mean = None
+        self._deg_cnt = None
+        self.pos = None           # for a transposed graph: index into the source CSR
+        self.dinv = None
+
+    # ---- construction ----------------------------------------------------
+    @classmethod
+    def from_edge_index(cls, edge_index, num_nodes, edge_weight=None, *, dst_row=1,
+                        remove_self_loops=False, add_self_loops=False, keep_loop_weight=False,
+                        fill=1.0, validate=False):
+        """edge_index: LongTensor [2, E] on the GPU.  dst_row=1 is PyG's
+        source_to_target flow (edge_index[1] = destination i); dst_row=0 is the
+        TF path's SparseAdj convention (edge_index[0] = row = destination)."""
+        _require_hip(edge_index, "edge_index")
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError("edge_index must be [2, E]")
+        L = lib()
+        dev = edge_index.device
+        ei = edge_index.to(torch.int64)
+        dst = ei[dst_row].contiguous()
+        src = ei[1 - dst_row].contiguous()
+        E, N = dst.numel(), int(num_nodes)
+        w = None
+        if edge_weight is not None:
+            _require_hip(edge_weight, "edge_weight")
+            w = edge_weight.detach().to(torch.float32).contiguous()
+        flags = (_lib.COO_REMOVE_SELF_LOOPS if remove_self_loops else 0) | \
+                (_lib.COO_ADD_SELF_LOOPS if add_self_loops else 0) | \
+                (_lib.COO_KEEP_LOOP_WEIGHT if keep_loop_weight else 0)
+        with torch.cuda.device(dev):
+            if validate:
+                bad = torch.zeros(1, dtype=torch.int32, device=dev)
+                check(L.mp_check_edge_index(ptr(dst), ptr(src), E, N, ptr(bad), _stream()))
+                if int(bad.item()):
+                    raise ValueError(f"edge_index has {int(bad.item())} entries outside [0, {N})")
+            cap = E + (N if add_self_loops else 0)
+            need = C.c_size_t(0)
+            check(L.mp_csr_from_coo_ws_bytes(E, N, C.byref(need)))
+            ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+            rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+            col = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+            weighted = w is not None or (add_self_loops and float(fill) != 1.0)
+            val = torch.empty(max(cap, 1), dtype=torch.float32, device=dev) if weighted else None
+            eid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+            check(L.mp_csr_from_coo(ptr(dst), ptr(src), ptr(w), E, N, flags, float(fill), ptr(rowptr),
+                                    ptr(col), ptr(val), ptr(eid), ptr(ws), need.value, _stream()),
+                  "mp_csr_from_coo")
+            nnz = int(rowptr[N].item())
+        g = cls(rowptr, col[:nnz], None if val is None else val[:nnz], eid[:nnz], N, nnz)
+        return g
+
+    @classmethod
+    def from_csr(cls, rowptr, col, val, num_nodes):
+        _require_hip(rowptr, "rowptr")
+        return cls(rowptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous(),
+                   None if val is None else val.to(torch.float32).contiguous(), None,
+                   num_nodes, col.numel())
+
+    def with_values(self, val):
+        """same sparsity pattern (and plan / transpose pattern), other entry values"""
+        g = CSRGraph(self.rowptr, self.col, val, self.eid, self.num_nodes, self.nnz)
+        g._plan = self._plan
+        return g
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    # ---- plan --------------------------------------------------------------
+    def plan(self):
+        if self._plan is None:
+            L = lib()
+            with torch.cuda.device(self.device):
+                nb = C.c_size_t(0)
+                check(L.mp_spmm_plan_bytes(self.num_nodes, self.nnz, C.byref(nb)))
+                blob = torch.empty(nb.value // 4, dtype=torch.int32, device=self.device)
+                counts = (C.c_int32 * 8)()
+                check(L.mp_spmm_plan_build(ptr(self.rowptr), self.num_nodes, self.nnz, ptr(blob),
+                                           nb.value, counts, _stream()), "mp_spmm_plan_build")
+            self._plan = (blob, counts)
+        return self._plan
+
+    # ---- derived graphs ----------------------------------------------------
+    def transpose(self):
+        """CSR of A^T (rows = sources) with values permuted; cached."""
+        if self._t is None:
+            L = lib()
+            N, nnz, dev = self.num_nodes, self.nnz, self.device
+            with torch.cuda.device(dev):
+                nb = C.c_size_t(0)
+                check(L.mp_csr_transpose_ws_bytes(nnz, N, C.byref(nb)))
+                ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+                t_rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+                t_col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+                t_val = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev) if self.val is not None else None
+                pos = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+                check(L.mp_csr_transpose(ptr(self.rowptr), ptr(self.col), ptr(self.val), N, nnz,
+                                         ptr(t_rowptr), ptr(t_col), ptr(t_val), ptr(pos), ptr(ws),
+                                         nb.value, _stream()), "mp_csr_transpose")
+            t = CSRGraph(t_rowptr, t_col[:nnz], None if t_val is None else t_val[:nnz], None, N, nnz)
+            t.pos = pos[:nnz]
+            self._t = t
+        return self._t
+
+    def transpose_with(self, val):
+        """transpose pattern of this graph carrying other per-entry values"""
+        t = self.transpose()
+        g = CSRGraph(t.rowptr, t.col, val[t.pos.long()] if val is not None else None, None,
+                     t.num_nodes, t.nnz)
+        g._plan = t._plan
+        g.pos = t.pos
+        return g
+
+    def row_ids(self):
+        L = lib()
+        out = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(L.mp_csr_row_ids(ptr(self.rowptr), self.num_nodes, self.nnz, ptr(out), _stream()))
+        return out[:self.nnz]
+
+    def entry_counts(self):
+        """number of stored entries per row (the divisor of reduce='mean')"""
+        if self._deg_cnt is None:
+            self._deg_cnt = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
+        return self._deg_cnt
+
+    def transpose_mean(self):
+        """A^T with entry (j <- i) = val / count(i): the backward operator of reduce='mean'"""
+        if self._t_mean is None:
+            inv = 1.0 / self.entry_counts().clamp(min=1.0)
+            per_entry = inv[self.row_ids().long()]
+            if self.val is not None:
+                per_entry = per_entry * self.val
+            self._t_mean = self.transpose_with(per_entry)
+        return self._t_mean
+
+    def degree(self, axis="row"):
+        L = lib()
+        deg = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(L.mp_csr_degree(ptr(self.rowptr), ptr(self.col), ptr(self.val), self.num_nodes, self.nnz,
+                                  _lib.AXIS_ROW if axis == "row" else _lib.AXIS_COL, ptr(deg), _stream()))
+        return deg
+
+    def gcn_norm(self, deg_axis="row"):
+        """D^-1/2 A D^-1/2 on the stored entries (self-loops are a from_edge_index option).
+        deg_axis='row': degree by destination (TfgIDLayer.py:549); 'col': by source (idconv.py:143-144)."""
+        L = lib()
+        N, nnz, dev = self.num_nodes, self.nnz, self.device
+        val_out = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+        dinv = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.mp_gcn_norm_edges(ptr(self.rowptr), ptr(self.col), ptr(self.val), N, nnz,
+                                      _lib.AXIS_ROW if deg_axis == "row" else _lib.AXIS_COL,
+                                      ptr(val_out), ptr(dinv), _stream()), "mp_gcn_norm_edges")
+        g = self.with_values(val_out[:nnz])
+        g.dinv = dinv[:N]
+        g._t = None
+        return g
+
+    def mark_ids(self, id_index):
+        """col with the sign bit set on entries whose source is an identity node"""
+        _require_hip(id_index, "id_index")
+        L = lib()
+        ids = id_index.to(torch.int64).contiguous()
+        flag = torch.empty(max(self.num_nodes, 1), dtype=torch.uint8, device=self.device)
+        out = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(L.mp_mark_id_sources(ptr(self.col), self.nnz, ptr(ids), ids.numel(), self.num_nodes,
+                                       ptr(flag), ptr(out), _stream()), "mp_mark_id_sources")
+        return out[:self.nnz]

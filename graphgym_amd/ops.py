@@ -1,0 +1,325 @@
+"""Differentiable operators over CSRGraph, each a thin autograd wrapper around one
+C-ABI entry point of libmpengine.so (include/mp_engine.h).
+
+    spmm(g, x, reduce)           SparseAdj.matmul (sparse_adj.py:91-97); PyG propagate
+    idgnn_aggregate(g, id, x)    two-branch form of gcn_id (TfgIDLayer.py:510-517)
+    index_add_rows(h, id, u)     tensor_scatter_nd_add / index_add_ (K10)
+    edge_softmax / sddmm_*       GAT pieces (TfgIDLayer.py:333-355; idconv.py:317-332)
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr
+from .graph import CSRGraph, _require_hip, _stream
+
+
+def _f32c(t, name):
+    _require_hip(t, name)
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (the path aggregates in fp32), got {t.dtype}")
+    return t if t.stride(-1) == 1 and t.dim() == 2 else t.contiguous()
+
+
+def _raw_spmm(g, x, reduce, S=None, self_scale=0.0, bias=None, relu=False, want_argmax=False,
+              col_override=None):
+    """one launch of mp_spmm_csr_f32; x [n_src, d] -> y [N, d]"""
+    L = lib()
+    N, d = g.num_nodes, x.size(1)
+    y = torch.empty((N, d), dtype=torch.float32, device=x.device)
+    argmax = torch.empty((N, d), dtype=torch.int32, device=x.device) if want_argmax else None
+    plan, counts = g.plan()
+    with torch.cuda.device(x.device):
+        nb = C.c_size_t(0)
+        check(L.mp_spmm_ws_bytes(counts, d, reduce, 0, C.byref(nb)))
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=x.device) if nb.value else None
+        col = g.col if col_override is None else col_override
+        check(L.mp_spmm_csr_f32(ptr(g.rowptr), ptr(col), ptr(g.val), N, ptr(plan), counts,
+                                ptr(x), x.stride(0), ptr(y), y.stride(0), d, reduce,
+                                ptr(S), S.stride(0) if S is not None else 0, float(self_scale),
+                                ptr(bias), _lib.ACT_RELU if relu else _lib.ACT_NONE, ptr(argmax),
+                                ptr(ws), nb.value, _stream()), "mp_spmm_csr_f32")
+    return y, argmax
+
+
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, g, reduce, self_scale, relu):
+        x = _f32c(x, "x")
+        if x.size(0) != g.num_nodes:
+            raise ValueError(f"x has {x.size(0)} rows, graph has {g.num_nodes} nodes")
+        S = x if self_scale != 0.0 else None
+        b = None if bias is None else bias.detach().contiguous()
+        y, argmax = _raw_spmm(g, x, reduce, S=S, self_scale=self_scale, bias=b, relu=relu,
+                              want_argmax=(reduce == _lib.MAX))
+        ctx.g, ctx.reduce, ctx.self_scale, ctx.relu = g, reduce, self_scale, relu
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(y if relu else None, argmax)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, argmax = ctx.saved_tensors
+        g = ctx.g
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = dy * (y > 0)
+        dbias = dy.sum(0) if ctx.has_bias else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            S = dy if ctx.self_scale != 0.0 else None
+            if ctx.reduce == _lib.SUM:
+                gt = g.transpose()
+                dx, _ = _raw_spmm(gt, dy, _lib.SUM, S=S, self_scale=ctx.self_scale)
+            elif ctx.reduce == _lib.MEAN:
+                gt = g.transpose_mean()
+                dx, _ = _raw_spmm(gt, dy, _lib.SUM, S=S, self_scale=ctx.self_scale)
+            else:
+                L = lib()
+                N, d = dy.shape
+                dx = torch.zeros((g.num_nodes, d), dtype=torch.float32, device=dy.device)
+                with torch.cuda.device(dy.device):
+                    check(L.mp_spmm_max_bwd_f32(ptr(g.col), ptr(g.val), ptr(argmax), ptr(dy), dy.stride(0),
+                                                N, d, ptr(dx), dx.stride(0), _stream()), "mp_spmm_max_bwd_f32")
+                if ctx.self_scale != 0.0:
+                    dx = dx + ctx.self_scale * dy
+        return dx, dbias, None, None, None, None
+
+
+def spmm(g, x, reduce="sum", self_scale=0.0, bias=None, relu=False):
+    """y[i] = act( reduce_{j in N(i)} w_ij x[j] + self_scale * x[i] + bias )
+
+    reduce: 'sum'/'add' | 'mean' | 'max'.  The gradient flows to x and bias; entry values
+    of g are constants here (attention weights go through spmm_edge_values)."""
+    return _SpMM.apply(x, bias, g, _lib.REDUCE[reduce], float(self_scale), bool(relu))
+
+
+class _IdAgg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, id_index, col_marked):
+        x = _f32c(x, "x")
+        L = lib()
+        N, d = g.num_nodes, x.size(1)
+        P = torch.empty((N, d), dtype=torch.float32, device=x.device)
+        Q = torch.empty((N, d), dtype=torch.float32, device=x.device)
+        plan, counts = g.plan()
+        with torch.cuda.device(x.device):
+            nb = C.c_size_t(0)
+            check(L.mp_spmm_ws_bytes(counts, d, _lib.SUM, 1, C.byref(nb)))
+            ws = torch.empty(nb.value, dtype=torch.uint8, device=x.device) if nb.value else None
+            check(L.mp_idgnn_agg_f32(ptr(g.rowptr), ptr(col_marked), ptr(g.val), N, ptr(plan), counts,
+                                     ptr(x), x.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0), d,
+                                     ptr(ws), nb.value, _stream()), "mp_idgnn_agg_f32")
+        ctx.g = g
+        ctx.save_for_backward(id_index)
+        return P, Q
+
+    @staticmethod
+    def backward(ctx, dP, dQ):
+        (id_index,) = ctx.saved_tensors
+        gt = ctx.g.transpose()
+        dx, _ = _raw_spmm(gt, dP.contiguous(), _lib.SUM)
+        # Q = A S x  =>  dx[id] += (A^T dQ)[id]
+        t, _ = _raw_spmm(gt, dQ.contiguous(), _lib.SUM)
+        dx.index_add_(0, id_index, t.index_select(0, id_index))
+        return dx, None, None, None
+
+
+def idgnn_aggregate(g, id_index, x, col_marked=None):
+    """(P, Q) with P = A x and Q = A S x, S selecting the identity nodes' rows: one pass over
+    the edges.  P @ W + Q @ W_id equals A (x W + S x W_id) of gcn_id (TfgIDLayer.py:510-517)."""
+    if col_marked is None:
+        col_marked = g.mark_ids(id_index)
+    return _IdAgg.apply(x, g, id_index.to(torch.int64), col_marked)
+
+
+class _IndexAddRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, id_index, u):
+        h = _f32c(h, "h").clone()
+        u = _f32c(u, "u")
+        L = lib()
+        ids = id_index.to(torch.int64).contiguous()
+        with torch.cuda.device(h.device):
+            check(L.mp_rows_scatter_add_f32(ptr(h), h.stride(0), ptr(ids), ids.numel(), h.size(1),
+                                            ptr(u), u.stride(0), _stream()), "mp_rows_scatter_add_f32")
+        ctx.save_for_backward(ids)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        (ids,) = ctx.saved_tensors
+        return dh, None, gather_rows(dh.contiguous(), ids)
+
+
+def index_add_rows(h, id_index, u):
+    """out = h ; out[id[k]] += u[k]   (tensor_scatter_nd_add, TfgIDLayer.py:107,165,330,515;
+    index_add_, idconv.py:67,155,251,310,375)"""
+    return _IndexAddRows.apply(h, id_index, u)
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ids):
+        x = _f32c(x, "x")
+        L = lib()
+        ids = ids.to(torch.int64).contiguous()
+        out = torch.empty((ids.numel(), x.size(1)), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(L.mp_rows_gather_f32(ptr(x), x.stride(0), ptr(ids), ids.numel(), x.size(1), ptr(out),
+                                       out.stride(0), _stream()), "mp_rows_gather_f32")
+        ctx.save_for_backward(ids)
+        ctx.n = x.size(0)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        dx = torch.zeros((ctx.n, dout.size(1)), dtype=torch.float32, device=dout.device)
+        L = lib()
+        dout = dout.contiguous()
+        with torch.cuda.device(dout.device):
+            check(L.mp_rows_scatter_add_f32(ptr(dx), dx.stride(0), ptr(ids), ids.numel(), dx.size(1),
+                                            ptr(dout), dout.stride(0), _stream()))
+        return dx, None
+
+
+def gather_rows(x, ids):
+    """x[ids]  (tf.gather / index_select of the identity rows)"""
+    return _GatherRows.apply(x, ids)
+
+
+# ---- attention pieces --------------------------------------------------------
+
+def _raw_sddmm_dot(g, A, B, heads, scale):
+    L = lib()
+    s = torch.empty(max(g.nnz, 1) * heads, dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        check(L.mp_sddmm_dot_f32(ptr(g.rowptr), ptr(g.col), g.num_nodes, g.nnz, ptr(A), A.stride(0),
+                                 ptr(B), B.stride(0), A.size(1), heads, float(scale), ptr(s), _stream()),
+              "mp_sddmm_dot_f32")
+    return s[:g.nnz * heads].view(g.nnz, heads)
+
+
+def _raw_spmm_heads(g, a, V, heads):
+    L = lib()
+    y = torch.empty((g.num_nodes, V.size(1)), dtype=torch.float32, device=V.device)
+    with torch.cuda.device(V.device):
+        check(L.mp_spmm_heads_f32(ptr(g.rowptr), ptr(g.col), ptr(a), g.num_nodes, heads, ptr(V),
+                                  V.stride(0), ptr(y), y.stride(0), V.size(1), _stream()),
+              "mp_spmm_heads_f32")
+    return y
+
+
+class _SddmmDot(torch.autograd.Function):
+    """s[e,h] = scale * <Q[row_e, slice h], K[col_e, slice h]>"""
+    @staticmethod
+    def forward(ctx, Q, K, g, heads, scale):
+        Q, K = _f32c(Q, "Q"), _f32c(K, "K")
+        ctx.g, ctx.heads, ctx.scale = g, heads, scale
+        ctx.save_for_backward(Q, K)
+        return _raw_sddmm_dot(g, Q, K, heads, scale)
+
+    @staticmethod
+    def backward(ctx, ds):
+        Q, K = ctx.saved_tensors
+        g, heads = ctx.g, ctx.heads
+        ds = (ds * ctx.scale).contiguous()
+        # dQ[i, slice h] = sum_e ds[e,h] K[col_e, slice h]   (an aggregation over in-edges)
+        dQ = _raw_spmm_heads(g, ds, K, heads)
+        # dK[j, slice h] = sum_{e: col_e = j} ds[e,h] Q[row_e, slice h]   (over out-edges)
+        gt = g.transpose()
+        dK = _raw_spmm_heads(gt, ds[gt.pos.long()].contiguous(), Q, heads)
+        return dQ, dK, None, None, None
+
+
+def sddmm_dot(g, Q, K, heads=1, scale=1.0):
+    return _SddmmDot.apply(Q, K, g, int(heads), float(scale))
+
+
+class _SddmmAdd(torch.autograd.Function):
+    """s[e] = leaky_relu(ai[row_e] + aj[col_e])"""
+    @staticmethod
+    def forward(ctx, ai, aj, g, slope):
+        L = lib()
+        ai, aj = ai.contiguous(), aj.contiguous()
+        s = torch.empty(max(g.nnz, 1), dtype=torch.float32, device=ai.device)
+        with torch.cuda.device(ai.device):
+            check(L.mp_sddmm_add_f32(ptr(g.rowptr), ptr(g.col), g.num_nodes, g.nnz, ptr(ai), ptr(aj),
+                                     float(slope), ptr(s), _stream()), "mp_sddmm_add_f32")
+        s = s[:g.nnz]
+        ctx.g, ctx.slope = g, slope
+        ctx.save_for_backward(s)
+        return s.view(g.nnz, 1)
+
+    @staticmethod
+    def backward(ctx, ds):
+        (s,) = ctx.saved_tensors
+        g = ctx.g
+        gs = ds.reshape(-1) * torch.where(s > 0, torch.ones_like(s), torch.full_like(s, ctx.slope))
+        dai = torch.zeros(g.num_nodes, dtype=torch.float32, device=s.device)
+        daj = torch.zeros(g.num_nodes, dtype=torch.float32, device=s.device)
+        dai.index_add_(0, g.row_ids().long(), gs)
+        daj.index_add_(0, g.col.long(), gs)
+        return dai, daj, None, None
+
+
+def sddmm_add(g, ai, aj, slope=0.2):
+    return _SddmmAdd.apply(ai, aj, g, float(slope))
+
+
+class _EdgeSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s, g):
+        L = lib()
+        s = s.contiguous()
+        heads = s.size(1)
+        p = torch.empty_like(s)
+        with torch.cuda.device(s.device):
+            check(L.mp_csr_row_softmax_f32(ptr(g.rowptr), g.num_nodes, heads, ptr(s), ptr(p), _stream()),
+                  "mp_csr_row_softmax_f32")
+        ctx.g = g
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        L = lib()
+        g = ctx.g
+        dp = dp.contiguous()
+        ds = torch.empty_like(p)
+        with torch.cuda.device(p.device):
+            check(L.mp_csr_row_softmax_bwd_f32(ptr(g.rowptr), g.num_nodes, p.size(1), ptr(p), ptr(dp),
+                                               ptr(ds), _stream()), "mp_csr_row_softmax_bwd_f32")
+        return ds, None
+
+
+def edge_softmax(g, s):
+    """softmax of the per-entry scores over each destination row, per head; s [nnz, H]"""
+    return _EdgeSoftmax.apply(s, g)
+
+
+class _SpmmEdgeValues(torch.autograd.Function):
+    """y[i, slice h] = sum_e a[e,h] V[col_e, slice h], differentiable in a and V"""
+    @staticmethod
+    def forward(ctx, a, V, g, heads):
+        a, V = a.contiguous(), _f32c(V, "V")
+        ctx.g, ctx.heads = g, heads
+        ctx.save_for_backward(a, V)
+        return _raw_spmm_heads(g, a, V, heads)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, V = ctx.saved_tensors
+        g, heads = ctx.g, ctx.heads
+        dy = dy.contiguous()
+        da = _raw_sddmm_dot(g, dy, V, heads, 1.0)
+        gt = g.transpose()
+        dV = _raw_spmm_heads(gt, a[gt.pos.long()].contiguous(), dy, heads)
+        return da, dV, None, None
+
+
+def spmm_edge_values(g, a, V, heads=1):
+    return _SpmmEdgeValues.apply(a, V, g, int(heads))

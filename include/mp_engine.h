@@ -1,0 +1,256 @@
+/*
+ * mp_engine.h — C ABI of the MI355X message-passing engine (libmpengine.so).
+ *
+ * This is the drop-in boundary for GraphGym's neighbour-aggregation hot path.
+ * The reference has no native layer (it is pure Python over torch-scatter /
+ * TensorFlow ops), so every entry point below cites the *Python* call site
+ * whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch / C++ types; all pointers are DEVICE
+ *     pointers unless the parameter name ends in `_host`;
+ *   - every function returns an mp_status (0 = ok); nothing throws;
+ *   - the caller owns every buffer (outputs and workspaces); nothing is
+ *     allocated or freed inside the library;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*);
+ *     functions do not synchronise unless their comment says so;
+ *   - matrices are row-major fp32 with an explicit leading dimension (in
+ *     elements); indices inside the engine are int32, the COO boundary takes
+ *     the int64 `edge_index` tensors GraphGym batches carry;
+ *   - row r of a CSR holds the in-edges of DESTINATION node r; `col` holds
+ *     SOURCE node ids (SparseAdj: edge_index[0] = row, [1] = col,
+ *     sparse_adj.py:50-56; PyG flow source_to_target: edge_index[1] = i).
+ */
+#ifndef MP_ENGINE_H
+#define MP_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mp_stream_t; /* hipStream_t */
+
+enum mp_status {
+  MP_OK = 0,
+  MP_ERR_INVALID_ARG = 1, /* null pointer, negative size, bad enum */
+  MP_ERR_UNSUPPORTED = 2, /* e.g. nnz >= 2^31 */
+  MP_ERR_WORKSPACE = 3,   /* workspace too small */
+  MP_ERR_HIP = 4,         /* a HIP runtime call failed; see mp_last_hip_error */
+  MP_ERR_ALIGNMENT = 5    /* pointer / leading dimension not aligned as required */
+};
+
+enum mp_reduce { MP_SUM = 0, MP_MEAN = 1, MP_MAX = 2 };
+
+/* mp_csr_from_coo flags */
+enum mp_coo_flags {
+  MP_COO_REMOVE_SELF_LOOPS = 1, /* torch_geometric.utils.remove_self_loops (idconv.py:302,370) */
+  MP_COO_ADD_SELF_LOOPS = 2,    /* append one (i,i) entry per node: tfg add_self_loop_edge via
+                                   SparseAdj.add_self_loop (sparse_adj.py:58-63, TfgIDLayer.py:298,547);
+                                   PyG add_self_loops (idconv.py:303) */
+  MP_COO_KEEP_LOOP_WEIGHT = 4   /* with REMOVE|ADD: an existing loop's weight replaces `fill` for
+                                   that node = PyG add_remaining_self_loops (idconv.py:52-53,140-141,232-233) */
+};
+
+/* degree axis for mp_csr_degree / mp_gcn_norm_edges */
+enum mp_axis {
+  MP_AXIS_ROW = 0, /* by destination: SparseAdj.reduce_sum(axis=-1) (sparse_adj.py:65-85, TfgIDLayer.py:549) */
+  MP_AXIS_COL = 1  /* by source: scatter_add(edge_weight, edge_index[0]) (idconv.py:56,144) */
+};
+
+/* epilogue activation fused into the aggregation's row flush (K15) */
+enum mp_act { MP_ACT_NONE = 0, MP_ACT_RELU = 1 };
+
+int mp_version(void);
+const char* mp_status_str(int status);
+/* text of the last failing HIP call on this thread ("" if none) */
+const char* mp_last_hip_error(void);
+
+/* ------------------------------------------------------------------ *
+ * Graph construction: COO edge list -> destination-sorted CSR         *
+ * replaces: SparseAdj.__init__/add_self_loop (sparse_adj.py:18-63),   *
+ *   add_remaining_self_loops / remove_self_loops / add_self_loops     *
+ *   call sites in idconv.py:52,140,232,302-304,370                    *
+ * ------------------------------------------------------------------ */
+
+/* bytes of workspace mp_csr_from_coo needs for E input edges, N nodes */
+int mp_csr_from_coo_ws_bytes(int64_t E, int64_t N, size_t* bytes_host);
+
+/*
+ * dst/src: [E] int64 node ids in [0,N).  w: [E] fp32 or NULL (= all ones).
+ * Outputs (capacity E+N entries each; nnz = rowptr[N] afterwards):
+ *   rowptr [N+1] int32, col [cap] int32 (sorted by (row, col, input order)),
+ *   val [cap] fp32 (may be NULL when w == NULL and fill == 1: unweighted),
+ *   eid [cap] int32: input position of each entry, or -1-i for an inserted
+ *   loop of node i (may be NULL).
+ * Out-of-range node ids make the result undefined; validate on the host
+ * (mp_check_edge_index) in debug paths.
+ */
+int mp_csr_from_coo(const int64_t* dst, const int64_t* src, const float* w,
+                    int64_t E, int64_t N, int flags, float fill,
+                    int32_t* rowptr, int32_t* col, float* val, int32_t* eid,
+                    void* ws, size_t ws_bytes, mp_stream_t stream);
+
+/* counts entries with dst or src outside [0,N) into *bad (device int32) */
+int mp_check_edge_index(const int64_t* dst, const int64_t* src, int64_t E,
+                        int64_t N, int32_t* bad, mp_stream_t stream);
+
+/* row id of every stored entry: row_of[e] = r for rowptr[r] <= e < rowptr[r+1] */
+int mp_csr_row_ids(const int32_t* rowptr, int64_t N, int64_t nnz,
+                   int32_t* row_of, mp_stream_t stream);
+
+/*
+ * Transpose (CSR of A^T, i.e. out-edges by source) for the backward pass
+ * dL/dX = A^T dL/dY (autodiff of gather + unsorted_segment_sum,
+ * sparse_adj.py:91-97; PyG propagate's backward).
+ * pos[k] = index in the source CSR of transposed entry k (so per-edge values
+ * such as attention coefficients can be permuted with one gather).
+ */
+int mp_csr_transpose_ws_bytes(int64_t nnz, int64_t N, size_t* bytes_host);
+int mp_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val,
+                     int64_t N, int64_t nnz,
+                     int32_t* t_rowptr, int32_t* t_col, float* t_val, int32_t* pos,
+                     void* ws, size_t ws_bytes, mp_stream_t stream);
+
+/* weighted degree: deg[i] = sum of val over row i (axis ROW) or column i (axis COL);
+ * val == NULL counts entries.  (K6: sparse_adj.py:84-85, idconv.py:56,144) */
+int mp_csr_degree(const int32_t* rowptr, const int32_t* col, const float* val,
+                  int64_t N, int64_t nnz, int axis, float* deg, mp_stream_t stream);
+
+/*
+ * GCN symmetric normalisation of the stored entries (K6-K8):
+ *   dinv = deg^-1/2 with inf/nan -> 0 ; val_out[e] = dinv[row] * val[e] * dinv[col]
+ * replaces gcn_norm_adj (TfgIDLayer.py:528-566) and GCNIDConvLayer.norm
+ * (idconv.py:132-148).  dinv_out [N] may be NULL.  val may be NULL (ones).
+ */
+int mp_gcn_norm_edges(const int32_t* rowptr, const int32_t* col, const float* val,
+                      int64_t N, int64_t nnz, int deg_axis,
+                      float* val_out, float* dinv_out, mp_stream_t stream);
+
+/* mark entries whose SOURCE is an identity node: col_out[e] = col[e] | 0x80000000
+ * when is_id[col[e]] != 0.  is_id: [N] uint8 scratch filled from id_index. */
+int mp_mark_id_sources(const int32_t* col, int64_t nnz, const int64_t* id_index,
+                       int64_t n_id, int64_t N, uint8_t* is_id, int32_t* col_out,
+                       mp_stream_t stream);
+
+/* ------------------------------------------------------------------ *
+ * Aggregation plan: nnz-balanced row segments + split of hub rows     *
+ * (no counterpart in the reference; built once per graph and cached)  *
+ * ------------------------------------------------------------------ */
+/* tunables of the segmentation (process-wide; a plan must be used under the config it
+ * was built with — its counts carry that config): a segment is a run of whole rows of
+ * cost ~seg_cost (1 per stored entry + row_cost per row); rows with more than hub_deg
+ * entries are split into pieces of piece_edges.  Defaults 320 / 4 / 1024 / 256. */
+int mp_spmm_plan_config(int seg_cost, int row_cost, int hub_deg, int piece_edges);
+int mp_spmm_plan_bytes(int64_t N, int64_t nnz, size_t* bytes_host);
+/* counts_host[8] <- {n_seg, n_hub, n_piece, cap_hub, cap_piece, seg_cost, hub_deg,
+ * piece_edges}; SYNCHRONISES `stream` (once per graph) */
+int mp_spmm_plan_build(const int32_t* rowptr, int64_t N, int64_t nnz,
+                       int32_t* plan, size_t plan_bytes, int32_t* counts_host,
+                       mp_stream_t stream);
+/* workspace bytes for an aggregation of width d with this plan */
+int mp_spmm_ws_bytes(const int32_t* counts_host, int32_t d, int reduce,
+                     int two_branch, size_t* bytes_host);
+
+/* ------------------------------------------------------------------ *
+ * The hot path: Y = reduce_{e in row r} val[e] * X[col[e], :]         *
+ * replaces SparseAdj.matmul (sparse_adj.py:91-97) = tf.gather * w ->  *
+ * unsorted_segment_sum; PyG MessagePassing.propagate + torch_scatter  *
+ * (idconv.py:89,177,235,315,371; generalconv.py:86); mean_reducer     *
+ * (TfgIDLayer.py:98); aggr='max' (generalconv.py:18).                 *
+ * ------------------------------------------------------------------ */
+/*
+ * X [n_src, d] (ldx), Y [N, d] (ldy).  val NULL = unweighted.
+ * reduce: MP_SUM | MP_MEAN (sum / row entry count; empty row -> 0) |
+ *         MP_MAX (empty row -> 0; argmax [N, d] int32 receives the CSR entry
+ *         index of the winner, -1 for empty rows; may be NULL).
+ * Epilogue, applied per output row before the store (K15, K17):
+ *   y = act( y + self_scale * S[r, :] + bias )
+ *   S (lds) NULL = no self term (GIN's (1+eps)*x_i: TfgIDLayer.py:157-159,
+ *   idconv.py:371); bias [d] NULL = none.
+ */
+int mp_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                    int64_t N, const int32_t* plan, const int32_t* counts_host,
+                    const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t d,
+                    int reduce, const float* S, int64_t lds, float self_scale,
+                    const float* bias, int act, int32_t* argmax,
+                    void* ws, size_t ws_bytes, mp_stream_t stream);
+
+/*
+ * ID-GNN two-branch aggregation in one pass over the edges (A7):
+ *   P[r,:] = sum_e val[e] * X[col[e],:]
+ *   Q[r,:] = sum_{e : source is an identity node} val[e] * X[col[e],:]
+ * so that  P W + Q W_id  ==  A_hat (X W + S X W_id)  of gcn_id
+ * (TfgIDLayer.py:510-517) / GCNIDConvLayer.forward (idconv.py:152-177).
+ * col must carry the identity mark of mp_mark_id_sources.
+ */
+int mp_idgnn_agg_f32(const int32_t* rowptr, const int32_t* col_marked, const float* val,
+                     int64_t N, const int32_t* plan, const int32_t* counts_host,
+                     const float* X, int64_t ldx, float* P, int64_t ldp,
+                     float* Q, int64_t ldq, int32_t d,
+                     void* ws, size_t ws_bytes, mp_stream_t stream);
+
+/* backward of MP_MAX: dX[col[e], c] += val[e] * dY[r,c] with e = argmax[r,c] >= 0
+ * (dX pre-zeroed by the caller; val NULL = ones) */
+int mp_spmm_max_bwd_f32(const int32_t* col, const float* val, const int32_t* argmax,
+                        const float* dY, int64_t ldy, int64_t N, int32_t d,
+                        float* dX, int64_t ldx, mp_stream_t stream);
+
+/* ------------------------------------------------------------------ *
+ * Identity-row update (K10): H[id[k], :] += U[k, :]                   *
+ * replaces tf.tensor_scatter_nd_add (TfgIDLayer.py:107,165,330,515)   *
+ * and x.index_add_(0, id, x_id) (idconv.py:67,155,251,310,375).       *
+ * Duplicate ids accumulate (atomics); GraphGym's ids are unique.      *
+ * ------------------------------------------------------------------ */
+int mp_rows_gather_f32(const float* X, int64_t ldx, const int64_t* idx, int64_t n,
+                       int32_t d, float* out, int64_t ldo, mp_stream_t stream);
+int mp_rows_scatter_add_f32(float* H, int64_t ldh, const int64_t* idx, int64_t n,
+                            int32_t d, const float* U, int64_t ldu, mp_stream_t stream);
+
+/* ------------------------------------------------------------------ *
+ * Attention pieces (K12, K13) for the GAT layers                      *
+ * ------------------------------------------------------------------ */
+/* dot-product scores: s[e*H+h] = scale * <Qm[row, h-th slice], Km[col, h-th slice]>
+ * (TfgIDLayer.py:333-339); H heads split the feature axis evenly. */
+int mp_sddmm_dot_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t nnz,
+                     const float* Qm, int64_t ldq, const float* Km, int64_t ldk,
+                     int32_t d, int32_t heads, float scale, float* s,
+                     mp_stream_t stream);
+/* additive scores: s[e] = leaky_relu(ai[row] + aj[col], slope) (idconv.py:319-326
+ * with ai = <z, att[:d]>, aj = <z, att[d:]> precomputed per node) */
+int mp_sddmm_add_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t nnz,
+                     const float* ai, const float* aj, float slope, float* s,
+                     mp_stream_t stream);
+/* softmax over each row's entries, per head: segment_softmax (sparse_adj.py:136-151),
+ * torch_geometric.utils.softmax (idconv.py:327).  In-place allowed. */
+int mp_csr_row_softmax_f32(const int32_t* rowptr, int64_t N, int32_t heads,
+                           const float* s, float* out, mp_stream_t stream);
+/* backward of the row softmax: ds = p * (dp - sum_row(p*dp)) */
+int mp_csr_row_softmax_bwd_f32(const int32_t* rowptr, int64_t N, int32_t heads,
+                               const float* p, const float* dp, float* ds,
+                               mp_stream_t stream);
+/* per-entry dot: g[e*H+h] = <A[row, slice h], B[col, slice h]> — gradient of an
+ * aggregation w.r.t. its edge values (A = dY, B = X) */
+int mp_sddmm_grad_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t nnz,
+                      const float* A, int64_t lda, const float* B, int64_t ldb,
+                      int32_t d, int32_t heads, float* g, mp_stream_t stream);
+/* multi-head weighted aggregation: Y[r, slice h] = sum_e a[e*H+h] * V[col[e], slice h] */
+int mp_spmm_heads_f32(const int32_t* rowptr, const int32_t* col, const float* a,
+                      int64_t N, int32_t heads, const float* V, int64_t ldv,
+                      float* Y, int64_t ldy, int32_t d, mp_stream_t stream);
+
+/* ------------------------------------------------------------------ *
+ * Host-side synthetic graph generator (bench / tests; not a device op) *
+ * Barabasi-Albert preferential attachment, m links per new node,      *
+ * family of datasets/syn_graph.py:42.  Writes m*(n-m) undirected      *
+ * (u > v) pairs to HOST arrays; returns the count via *n_edges_host.  *
+ * ------------------------------------------------------------------ */
+int mp_gen_ba_edges_host(int64_t n, int32_t m, uint64_t seed,
+                         int64_t* u_host, int64_t* v_host, int64_t* n_edges_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MP_ENGINE_H */
