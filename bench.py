@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the hot path (BASELINE.json: "aggregated edges/sec + achieved HBM GB/s,
+GCN d=256 on 100M-edge scale-free").
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the aggregation  Y = A_hat X  over one graph resident in HBM:
+A_hat = D^-1/2 (A + I) D^-1/2 of a Barabasi-Albert BA(10^7, 5) graph (about 1.1*10^8 stored
+entries incl. self loops), X [10^7, 256] fp32.  With N > 1 every rank owns its own graph of that
+size (weak scaling; independent units, no data-path collective — DESIGN.md §6).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the aggregation launch against HBM;
+`cpu_baseline` times the CPU oracle (the op-for-op restatement of the reference's CPU path) on a
+bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(n, nnz, d, weighted):
+    """SURVEY §8(d) gather model: every neighbour row read, every output row written once,
+    int32 column index (+ fp32 value) per stored entry, rowptr."""
+    return nnz * d * 4 + n * d * 4 + nnz * 4 + (nnz * 4 if weighted else 0) + (n + 1) * 4
+
+
+def cpu_baseline(g, x, seconds=12.0):
+    """oracle/ref_ops.coo_aggregate_sum_chunked on the leading edge chunks of the same graph"""
+    from oracle import ref_ops
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    n, d = x.shape
+    chunk = 4_000_000
+    take = min(g.nnz, 6 * chunk)
+    dst = g.row_ids()[:take].long().cpu()
+    src = g.col[:take].long().cpu()
+    w = g.val[:take].cpu() if g.val is not None else None
+    xc = x.cpu()
+    out = torch.zeros((n, d), dtype=torch.float32)
+    ref_ops.coo_aggregate_sum_chunked(dst[:200_000], src[:200_000], None if w is None else w[:200_000], xc, out,
+                                      chunk)  # touch pages / warm the thread pool
+    t0 = time.perf_counter()
+    done = ref_ops.coo_aggregate_sum_chunked(dst, src, w, xc, out, chunk, max_seconds=seconds)
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"first {done} of {g.nnz} stored entries of the same graph, same X (fp32, d={d}), "
+                      f"gather*scale -> index_add_ in 4M-edge chunks, {dt:.1f} s of CPU work"}
+
+
+def pmc_traffic(workload):
+    """per-launch HBM bytes from the committed rocprofv3 PMC passes (profiles/), if they match"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("workload") == workload:
+            return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nodes", type=int, default=10_000_000)
+    ap.add_argument("--m", type=int, default=5)
+    ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import graphgym_amd as ga
+    from graphgym_amd import _lib, dist as D, graphgen, ops
+
+    rank, local, world = D.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local)
+
+    n, d = args.nodes, args.d
+    ei = graphgen.ba_edge_index(n, args.m, seed=12345 + rank, device=dev)
+    g = ga.CSRGraph.from_edge_index(ei, n, add_self_loops=True).gcn_norm("row")
+    del ei
+    g.plan()
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+    x = torch.rand((n, d), device=dev, generator=gen) * 2 - 1
+    y = torch.empty((n, d), dtype=torch.float32, device=dev)
+    torch.cuda.empty_cache()
+
+    def step():
+        ops._raw_spmm(g, x, _lib.SUM, out=y)
+
+    for _ in range(args.warmup):
+        step()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record()
+        step()
+        stops[i].record()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    dt = D.all_reduce_max(dt, dev)
+    total_nnz = D.all_reduce_sum(g.nnz, dev)
+    launch_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / args.steps
+
+    if rank == 0:
+        balg = algorithmic_bytes(n, g.nnz, d, g.val is not None)
+        achieved = balg / (launch_ms * 1e-3) / 1e9
+        workload = f"gcn_norm_sum_d{d}_BA_n{n}_m{args.m}"
+        res = {
+            "metric": "aggregated edges/sec, GCN-normalised sum aggregation d=256 on a 10M-node/100M-edge scale-free graph",
+            "value": total_nnz * args.steps / dt,
+            "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "nodes_per_gpu": n, "stored_entries_per_gpu": g.nnz,
+                       "feature_dim": d, "reduce": "sum", "edge_weights": "D^-1/2 (A+I) D^-1/2",
+                       "graph": f"Barabasi-Albert BA({n},{args.m}) seed 12345+rank, symmetrised, deduplicated, self loops added",
+                       "index_dtype": "int32", "parallelism": f"{world} independent graph(s), one per GPU, no data-path collective"},
+            "hbm_gbps_algorithmic": achieved,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(workload),
+                         "algorithmic_bytes_per_launch": balg, "launch_ms": launch_ms,
+                         "kernel": "mp::agg_rows_kernel<4,SUM,weighted> (+ hub pieces/finalize, same launch group)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(g, x)
+        print(json.dumps(res), flush=True)
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

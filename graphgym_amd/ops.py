@@ -23,11 +23,11 @@ def _f32c(t, name):
 
 
 def _raw_spmm(g, x, reduce, S=None, self_scale=0.0, bias=None, relu=False, want_argmax=False,
-              col_override=None):
-    """one launch of mp_spmm_csr_f32; x [n_src, d] -> y [N, d]"""
+              col_override=None, out=None):
+    """one launch of mp_spmm_csr_f32; x [n_src, d] -> y [N, d] (written into `out` when given)"""
     L = lib()
     N, d = g.num_nodes, x.size(1)
-    y = torch.empty((N, d), dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty((N, d), dtype=torch.float32, device=x.device)
     argmax = torch.empty((N, d), dtype=torch.int32, device=x.device) if want_argmax else None
     plan, counts = g.plan()
     with torch.cuda.device(x.device):

@@ -1,0 +1,115 @@
+"""Host-side logic that needs no GPU: registry semantics, config, layer construction,
+sharding, and the N>1 gradient exchange over gloo (world_size 2)."""
+import os
+import socket
+import textwrap
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def test_registry_semantics_match_reference():
+    from graphgym_amd import register as R
+    d = {}
+    R.register("a", int, d)
+    with pytest.raises(KeyError, match="already pre-defined"):
+        R.register("a", float, d)                                    # register.py:6-10
+    import graphgym_amd.graphgym_plugin as plugin
+    for key in ["gcnconv", "sageconv", "gatconv", "ginconv", "generalconv", "idconv", "gcnidconv",
+                "sageidconv", "gatidconv", "ginidconv", "Tfg-gcnconv", "Tfg-sageconv", "Tfg-gatconv",
+                "Tfg-ginconv", "Tfg-idgcn", "Tfg-idsage", "Tfg-idgat", "Tfg-idgin"]:
+        assert R.layer_dict[key] is plugin.ALL_KEYS[key]
+    with pytest.raises(KeyError):
+        R.register_layer("gcnidconv", object)
+    assert plugin.install(override=True) == list(plugin.ALL_KEYS)    # re-import / re-install is idempotent
+
+
+def test_config_yaml_keys(tmp_path):
+    from graphgym_amd import config
+    y = tmp_path / "c.yaml"
+    y.write_text(textwrap.dedent("""
+        out_dir: results
+        dataset: {format: nx, name: scalefree, transform: ego}
+        gnn: {layers_mp: 3, dim_inner: 128, layer_type: Tfg-idgcn, agg: mean, l2norm: True}
+        optim: {base_lr: 0.01}
+    """))
+    c = config.load_cfg(str(y), target=config._defaults())
+    assert c.gnn.layer_type == "Tfg-idgcn" and c.gnn.dim_inner == 128 and c.gnn.agg == "mean"
+    assert c.dataset.transform == "ego" and c.gnn.normalize_adj is False and c.bn.eps == 1e-5
+
+
+def test_layer_parameters_are_named_and_shaped_like_the_reference():
+    from graphgym_amd import layers as L
+    m = L.GCNIDConv(8, 16, bias=True)
+    assert sorted(n for n, _ in m.named_parameters()) == ["model.bias", "model.weight", "model.weight_id"]
+    assert m.model.weight.shape == (8, 16) and float(m.model.bias.abs().sum()) == 0.0   # zeros init
+    assert L.GCNIDConv(8, 16).model.bias is None                                         # bias=False default
+    m = L.SAGEIDConv(8, 16)
+    assert m.model.weight.shape == (16, 16) and m.model.concat                           # 2*in with concat
+    m = L.GATIDConv(8, 16, bias=True)
+    assert m.model.att.shape == (1, 1, 32)
+    m = L.GINIDConv(8, 16)
+    assert isinstance(m.model.nn[0], torch.nn.Linear) and float(m.model.eps) == 0.0
+    assert "eps" in dict(m.model.named_buffers())
+    m = L.TfgIDSAGE(8, 16, bias=True)
+    assert m.model.self_kernel.shape == (8, 8) and m.model.id_kernel.shape == (8, 8) and m.model.bias.shape == (16,)
+    m = L.IDGCN(16)                                                                      # keras-style lazy build
+    assert m.kernel is None
+    m.build(5)
+    assert m.kernel.shape == (5, 16) and m.kernel_id.shape == (5, 16)
+    bound = (6.0 / (5 + 16)) ** 0.5
+    assert float(m.kernel.abs().max()) <= bound                                          # glorot_uniform
+
+
+def test_lpt_partition_balances_nnz():
+    from graphgym_amd.dist import lpt_partition
+    costs = [100, 1, 1, 1, 50, 49, 2, 98]
+    parts = lpt_partition(costs, 2)
+    assert sorted(i for p in parts for i in p) == list(range(8))
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert abs(loads[0] - loads[1]) <= 2
+    assert lpt_partition(costs, 2) == parts
+    assert lpt_partition([5], 4) == [[0], [], [], []]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from graphgym_amd import dist as D
+    r, _, w = D.init_from_env(device_type="cpu")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.ReLU(), torch.nn.Linear(3, 2))
+    # each rank owns different units -> different gradients
+    units = D.lpt_partition([10, 20, 30, 40], w)[r]
+    x = torch.arange(4 * 4, dtype=torch.float32).view(4, 4)[units] / 10.0
+    model(x).sum().backward()
+    local = [p.grad.clone() for p in model.parameters()]
+    bucket = D.GradBucket(model.parameters())
+    bucket.all_reduce_mean()
+    D.barrier()
+    tmax = D.all_reduce_max(float(r + 1), torch.device("cpu"))
+    tsum = D.all_reduce_sum(float(len(units)), torch.device("cpu"))
+    torch.save({"local": local, "avg": [p.grad.clone() for p in model.parameters()], "tmax": tmax,
+                "tsum": tsum, "units": units}, os.path.join(out, f"r{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_gradient_all_reduce_gloo_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(tmp_path / "r0.pt", weights_only=True)
+    b = torch.load(tmp_path / "r1.pt", weights_only=True)
+    assert sorted(a["units"] + b["units"]) == [0, 1, 2, 3]
+    for la, lb, ga, gb in zip(a["local"], b["local"], a["avg"], b["avg"]):
+        assert torch.allclose(ga, (la + lb) / 2, atol=1e-6)
+        assert torch.equal(ga, gb)                                   # ranks end with identical gradients
+    assert a["tmax"] == 2.0 and a["tsum"] == 4.0

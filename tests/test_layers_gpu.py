@@ -1,0 +1,296 @@
+"""Layer-level parity on the GPU: every layer_type key the engine serves, forward and
+backward, against the committed golden records (tests/golden/layers.npz, produced by the
+oracle's restatement of TfgIDLayer.py / idconv.py / the PyG and tf_geometric layers).
+
+The records carry the weights under the names of the reference's parameters, so loading
+them also checks that ours are named and shaped alike.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+F_IN, D = 8, 16
+TOL = 2e-5   # GEMMs (rocBLAS) reassociate differently from the CPU; aggregation itself is held to 1e-5 elsewhere
+
+
+def close(a, ref, tol=TOL):
+    a = a.detach().cpu().double()
+    ref = torch.from_numpy(np.asarray(ref)).double()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((a - ref).abs().max())
+    assert err <= tol * scale, f"max err {err:.3e} > {tol:.0e} * {scale:.3g}"
+
+
+def mlp2():
+    return nn.Sequential(nn.Linear(F_IN, D), nn.ReLU(), nn.Linear(D, D))
+
+
+def set_mlp(seq, z, key, prefix):
+    with torch.no_grad():
+        seq[0].weight.copy_(torch.from_numpy(z[f"{key}/param/{prefix}.0"]).t())
+        seq[0].bias.copy_(torch.from_numpy(z[f"{key}/param/{prefix}.1"]))
+        seq[2].weight.copy_(torch.from_numpy(z[f"{key}/param/{prefix}.2"]).t())
+        seq[2].bias.copy_(torch.from_numpy(z[f"{key}/param/{prefix}.3"]))
+
+
+def check_mlp_grads(seq, z, key, prefix):
+    close(seq[0].weight.grad.t(), z[f"{key}/grad/{prefix}.0"], 1e-4)
+    close(seq[0].bias.grad, z[f"{key}/grad/{prefix}.1"], 1e-4)
+    close(seq[2].weight.grad.t(), z[f"{key}/grad/{prefix}.2"], 1e-4)
+    close(seq[2].bias.grad, z[f"{key}/grad/{prefix}.3"], 1e-4)
+
+
+def load_named(mod, z, key, names, transpose=()):
+    with torch.no_grad():
+        for n in names:
+            p = mod
+            for part in n.split("."):
+                p = getattr(p, part)
+            src = torch.from_numpy(z[f"{key}/param/{n}"])
+            if n in transpose:
+                src = src.t()
+            assert p.shape == src.shape, (key, n, p.shape, src.shape)
+            p.copy_(src)
+
+
+def check_named_grads(mod, z, key, names, transpose=()):
+    for n in names:
+        p = mod
+        for part in n.split("."):
+            p = getattr(p, part)
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        if n in transpose:
+            g = g.t()
+        close(g, z[f"{key}/grad/{n}"], 1e-4)
+
+
+@pytest.fixture(scope="module")
+def rec(golden):
+    return golden("layers.npz")
+
+
+def run(layer_call, z, key, dev):
+    x = torch.from_numpy(z["x"]).to(dev).requires_grad_(True)
+    out = layer_call(x)
+    dy = torch.from_numpy(z["dy"]).to(dev)[:, :out.size(1)]
+    out.backward(dy)
+    close(out, z[f"{key}/out"])
+    close(x.grad, z[f"{key}/grad_x"], 1e-4)
+
+
+@pytest.mark.parametrize("order", ["transform_first", "aggregate_first"])
+def test_gcnidconv(dev, rec, order):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    ids = torch.from_numpy(rec["node_id_index"]).to(dev)
+    m = L.GCNIDConvLayer(F_IN, D, bias=True, order=order).to(dev)
+    names = ["weight", "weight_id", "bias"]
+    load_named(m, rec, "gcnidconv", names)
+    run(lambda x: m(x, ei, ids), rec, "gcnidconv", dev)
+    check_named_grads(m, rec, "gcnidconv", names)
+
+
+@pytest.mark.parametrize("agg", ["add", "mean", "max"])
+def test_idconv_and_generalconv(dev, rec, agg):
+    from graphgym_amd import layers as L
+    from graphgym_amd.config import cfg
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    ids = torch.from_numpy(rec["node_id_index"]).to(dev)
+    old = (cfg.gnn.agg, cfg.gnn.normalize_adj, cfg.gnn.self_msg)
+    try:
+        cfg.gnn.agg, cfg.gnn.normalize_adj, cfg.gnn.self_msg = agg, False, "concat"
+        m = L.GeneralIDConvLayer(F_IN, D, bias=True, order="transform_first").to(dev)
+        names = ["weight", "weight_id", "bias"]
+        load_named(m, rec, f"idconv_{agg}", names)
+        run(lambda x: m(x, ei, ids), rec, f"idconv_{agg}", dev)
+        check_named_grads(m, rec, f"idconv_{agg}", names)
+        m = L.GeneralConvLayer(F_IN, D, bias=True).to(dev)
+        names = ["weight", "weight_self", "bias"]
+        load_named(m, rec, f"generalconv_{agg}", names)
+        run(lambda x: m(x, ei), rec, f"generalconv_{agg}", dev)
+        check_named_grads(m, rec, f"generalconv_{agg}", names)
+    finally:
+        cfg.gnn.agg, cfg.gnn.normalize_adj, cfg.gnn.self_msg = old
+
+
+def test_sageidconv(dev, rec):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    ids = torch.from_numpy(rec["node_id_index"]).to(dev)
+    m = L.SAGEIDConvLayer(F_IN, D, bias=True, concat=True).to(dev)
+    names = ["weight", "weight_id", "bias"]
+    load_named(m, rec, "sageidconv", names)
+    run(lambda x: m(x, ei, ids), rec, "sageidconv", dev)
+    check_named_grads(m, rec, "sageidconv", names)
+
+
+def test_gatidconv(dev, rec):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    ids = torch.from_numpy(rec["node_id_index"]).to(dev)
+    m = L.GATIDConvLayer(F_IN, D, bias=True).to(dev)
+    names = ["weight", "weight_id", "att", "bias"]
+    load_named(m, rec, "gatidconv", names)
+    run(lambda x: m(x, ei, ids), rec, "gatidconv", dev)
+    check_named_grads(m, rec, "gatidconv", names)
+
+
+def test_ginidconv_and_ginconv(dev, rec):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    ids = torch.from_numpy(rec["node_id_index"]).to(dev)
+    m = L.GINIDConvLayer(mlp2(), mlp2()).to(dev)
+    set_mlp(m.nn, rec, "ginidconv", "nn")
+    set_mlp(m.nn_id, rec, "ginidconv", "nn_id")
+    run(lambda x: m(x, ei, ids), rec, "ginidconv", dev)
+    check_mlp_grads(m.nn, rec, "ginidconv", "nn")
+    check_mlp_grads(m.nn_id, rec, "ginidconv", "nn_id")
+    m = L.GINConvLayer(mlp2()).to(dev)
+    set_mlp(m.nn, rec, "ginconv", "nn")
+    run(lambda x: m(x, ei), rec, "ginconv", dev)
+    check_mlp_grads(m.nn, rec, "ginconv", "nn")
+
+
+@pytest.mark.parametrize("order", ["transform_first", "aggregate_first"])
+def test_gcnconv(dev, rec, order):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    m = L.GCNConvLayer(F_IN, D, bias=True, order=order).to(dev)
+    load_named(m, rec, "gcnconv", ["weight", "bias"])
+    run(lambda x: m(x, ei), rec, "gcnconv", dev)
+    check_named_grads(m, rec, "gcnconv", ["weight", "bias"])
+
+
+def test_sageconv(dev, rec):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    m = L.SAGEConvLayer(F_IN, D, bias=True).to(dev)
+    names = ["lin_l.weight", "lin_l.bias", "lin_r.weight"]
+    load_named(m, rec, "sageconv", names)
+    run(lambda x: m(x, ei), rec, "sageconv", dev)
+    check_named_grads(m, rec, "sageconv", names)
+
+
+def test_gatconv(dev, rec):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    m = L.GATConvLayer(F_IN, D, bias=True).to(dev)
+    with torch.no_grad():
+        m.lin_l.weight.copy_(torch.from_numpy(rec["gatconv/param/weight"]).t())
+        m.att_r.copy_(torch.from_numpy(rec["gatconv/param/att_dst"]).view(1, 1, D))
+        m.att_l.copy_(torch.from_numpy(rec["gatconv/param/att_src"]).view(1, 1, D))
+        m.bias.copy_(torch.from_numpy(rec["gatconv/param/bias"]))
+    run(lambda x: m(x, ei), rec, "gatconv", dev)
+    close(m.lin_l.weight.grad.t(), rec["gatconv/grad/weight"], 1e-4)
+    close(m.att_r.grad.view(1, D), rec["gatconv/grad/att_dst"], 1e-4)
+    close(m.att_l.grad.view(1, D), rec["gatconv/grad/att_src"], 1e-4)
+    close(m.bias.grad, rec["gatconv/grad/bias"], 1e-4)
+
+
+# ---- TF family ----------------------------------------------------------------------------
+@pytest.mark.parametrize("order", ["transform_first", "aggregate_first"])
+def test_tf_idgcn_and_gcn(dev, rec, order):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    ids = torch.from_numpy(rec["node_id_index"]).to(dev)
+    m = L.IDGCN(D, activation="relu", in_features=F_IN, order=order).to(dev)
+    names = ["kernel", "kernel_id", "bias"]
+    load_named(m, rec, "tf_idgcn", names)
+    run(lambda x: m([x, ei, ids]), rec, "tf_idgcn", dev)
+    check_named_grads(m, rec, "tf_idgcn", names)
+    m = L.GCN(D, activation=torch.relu, in_features=F_IN, order=order).to(dev)
+    load_named(m, rec, "tf_gcn", ["kernel", "bias"])
+    run(lambda x: m([x, ei, None]), rec, "tf_gcn", dev)
+    check_named_grads(m, rec, "tf_gcn", ["kernel", "bias"])
+
+
+def test_tf_idsage_and_sage(dev, rec):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    ids = torch.from_numpy(rec["node_id_index"]).to(dev)
+    m = L.IDSAGE(D, activation=torch.relu, in_features=F_IN).to(dev)
+    names = ["self_kernel", "id_kernel", "neighbor_kernel", "bias"]
+    load_named(m, rec, "tf_idsage", names)
+    run(lambda x: m([x, ei, ids]), rec, "tf_idsage", dev)
+    check_named_grads(m, rec, "tf_idsage", names)
+    m = L.MeanGraphSage(D, activation=torch.relu, in_features=F_IN).to(dev)
+    names = ["self_kernel", "neighbor_kernel", "bias"]
+    load_named(m, rec, "tf_sage", names)
+    run(lambda x: m([x, ei]), rec, "tf_sage", dev)
+    check_named_grads(m, rec, "tf_sage", names)
+    with pytest.raises(Exception):
+        L.IDSAGE(7, concat=True)                                   # odd units (TfgIDLayer.py:42-43)
+
+
+def test_tf_idgin_and_gin(dev, rec):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    ids = torch.from_numpy(rec["node_id_index"]).to(dev)
+    m = L.IDGIN(mlp2(), mlp2()).to(dev)
+    set_mlp(m.mlp_model, rec, "tf_idgin", "mlp")
+    set_mlp(m.mlp_id, rec, "tf_idgin", "mlp_id")
+    run(lambda x: m([x, ei, ids, None]), rec, "tf_idgin", dev)
+    check_mlp_grads(m.mlp_model, rec, "tf_idgin", "mlp")
+    check_mlp_grads(m.mlp_id, rec, "tf_idgin", "mlp_id")
+    m = L.GIN(mlp2()).to(dev)
+    set_mlp(m.mlp_model, rec, "tf_gin", "mlp")
+    run(lambda x: m([x, ei, None]), rec, "tf_gin", dev)
+    check_mlp_grads(m.mlp_model, rec, "tf_gin", "mlp")
+
+
+@pytest.mark.parametrize("heads", [1, 4])
+def test_tf_idgat(dev, rec, heads):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    ids = torch.from_numpy(rec["node_id_index"]).to(dev)
+    m = L.IDGAT(D, activation="relu", num_heads=heads, in_features=F_IN).to(dev)
+    names = ["query_kernel", "query_bias", "key_kernel", "key_bias", "kernel", "kernel_id", "bias"]
+    key = f"tf_idgat_h{heads}"
+    load_named(m, rec, key, names)
+    run(lambda x: m([x, ei, ids]), rec, key, dev)
+    check_named_grads(m, rec, key, names)
+
+
+def test_tf_gat(dev, rec):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    m = L.GAT(D, activation="relu", in_features=F_IN).to(dev)
+    names = ["query_kernel", "query_bias", "key_kernel", "key_bias", "kernel", "bias"]
+    load_named(m, rec, "tf_gat", names)
+    run(lambda x: m([x, ei]), rec, "tf_gat", dev)
+    check_named_grads(m, rec, "tf_gat", names)
+
+
+# ---- the GraphGym boundary: layer_dict[key](dim_in, dim_out, bias=...)(batch) ---------------
+def test_registered_keys_run_on_a_batch(dev, rec):
+    import graphgym_amd.graphgym_plugin as plugin
+    from graphgym_amd.register import layer_dict
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    ids = torch.from_numpy(rec["node_id_index"]).to(dev)
+    for key in plugin.ALL_KEYS:
+        layer = layer_dict[key](F_IN, D, bias=True).to(dev)
+        batch = types.SimpleNamespace(node_feature=torch.from_numpy(rec["x"]).to(dev), edge_index=ei,
+                                      node_id_index=ids)
+        out = layer(batch)
+        assert out is batch and batch.node_feature.shape == (int(rec["n"]), D), key
+        assert torch.isfinite(batch.node_feature).all(), key
+        batch.node_feature.sum().backward()
+        # one CSR per self-loop policy was cached on the batch and is reused by the next layer
+        assert hasattr(batch, "_mp_graph_cache"), key
+
+
+def test_cached_layer_raises_on_changed_edge_count(dev, rec):
+    from graphgym_amd import layers as L
+    ei = torch.from_numpy(rec["edge_index"]).to(dev)
+    ids = torch.from_numpy(rec["node_id_index"]).to(dev)
+    x = torch.from_numpy(rec["x"]).to(dev)
+    m = L.GCNIDConvLayer(F_IN, D, cached=True).to(dev)
+    m(x, ei, ids)
+    with pytest.raises(RuntimeError, match="Cached"):
+        m(x, ei[:, :-2], ids)                                       # idconv.py:157-163

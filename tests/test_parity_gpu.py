@@ -1,0 +1,420 @@
+"""Parity of the HIP path (through the C ABI: graphgym_amd.graph / ops -> libmpengine.so)
+against the CPU oracle and the committed golden vectors.
+
+Bars: integer / index work bit-exact; fp32 aggregation within 1e-5 (relative to the
+magnitude of the row being summed: |err| <= 1e-5 * max(1, max|ref|)), the tolerance
+BASELINE.json's north_star states.  The oracle is unpinned by the reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, ref, tol=1e-5):
+    a = a.detach().cpu().double()
+    ref = ref.detach().cpu().double() if isinstance(ref, torch.Tensor) else torch.from_numpy(np.asarray(ref)).double()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    if a.numel() == 0:
+        return
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((a - ref).abs().max())
+    assert err <= tol * scale, f"max err {err:.3e} > {tol:.0e} * {scale:.3g}"
+
+
+def csr_reference(dst, src, N, w=None):
+    """numpy restatement of the CSR order contract: stable sort by (dst, src)"""
+    dst, src = np.asarray(dst), np.asarray(src)
+    order = np.lexsort((np.arange(dst.size), src, dst))
+    rowptr = np.zeros(N + 1, dtype=np.int64)
+    np.add.at(rowptr, dst + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    return rowptr, src[order], order, (None if w is None else np.asarray(w)[order])
+
+
+# --------------------------------------------------------------------------- graph build
+def test_csr_build_is_bit_exact(dev):
+    import graphgym_amd as ga
+    g = torch.Generator().manual_seed(11)
+    for N, E in [(1, 0), (5, 0), (1, 3), (17, 200), (1000, 20000), (300, 50000)]:
+        ei = torch.randint(0, N, (2, E), generator=g)
+        w = torch.rand(E, generator=g)
+        G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev), validate=True)
+        rowptr, col, order, wv = csr_reference(ei[1].numpy(), ei[0].numpy(), N, w.numpy())
+        assert G.nnz == E
+        assert (G.rowptr.cpu().numpy() == rowptr).all()
+        assert (G.col.cpu().numpy() == col).all()
+        assert (G.eid.cpu().numpy() == order).all()
+        assert (G.val.cpu().numpy() == wv).all()
+        # TF convention: edge_index[0] is the destination row
+        G2 = ga.CSRGraph.from_edge_index(ei.to(dev), N, dst_row=0)
+        rowptr2, col2, _, _ = csr_reference(ei[0].numpy(), ei[1].numpy(), N)
+        assert (G2.rowptr.cpu().numpy() == rowptr2).all() and (G2.col.cpu().numpy() == col2).all()
+        assert G2.val is None
+
+
+def test_edge_index_validation(dev):
+    import graphgym_amd as ga
+    ei = torch.tensor([[0, 5], [1, 0]], device=dev)
+    with pytest.raises(ValueError):
+        ga.CSRGraph.from_edge_index(ei, 3, validate=True)
+
+
+def _dense(G):
+    A = torch.zeros(G.num_nodes, G.num_nodes, dtype=torch.float64)
+    rows = G.row_ids().cpu().long()
+    v = torch.ones(G.nnz, dtype=torch.float64) if G.val is None else G.val.cpu().double()
+    A.index_put_((rows, G.col.cpu().long()), v, accumulate=True)
+    return A
+
+
+def test_self_loop_policies_match_oracle(dev):
+    import graphgym_amd as ga
+    ei = torch.tensor([[0, 1, 1, 2, 3, 3, 0], [1, 1, 2, 2, 0, 3, 1]])
+    w = torch.tensor([1., 5., 2., 7., 3., 4., 0.5])
+    N = 5
+
+    def dense_of(e, ww):
+        A = torch.zeros(N, N, dtype=torch.float64)
+        A.index_put_((e[1], e[0]), ww.double(), accumulate=True)
+        return A
+    # PyG add_remaining_self_loops (existing loop weight kept; idconv.py:140-141)
+    e, ww = R.add_remaining_self_loops(ei, w, 2.0, N)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev), remove_self_loops=True, add_self_loops=True,
+                                    keep_loop_weight=True, fill=2.0)
+    assert G.nnz == e.size(1)
+    # two loops on node 1/3 would be ambiguous; here each node has at most one, so exact
+    assert torch.equal(_dense(G), dense_of(e, ww))
+    # remove_self_loops (idconv.py:370)
+    e, ww = R.remove_self_loops(ei, w)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev), remove_self_loops=True)
+    assert G.nnz == e.size(1) and torch.equal(_dense(G), dense_of(e, ww))
+    # remove + add_self_loops (idconv.py:302-304)
+    e, _ = R.remove_self_loops(ei)
+    e, _ = R.add_self_loops(e, None, 1.0, N)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N, None, remove_self_loops=True, add_self_loops=True)
+    assert G.nnz == e.size(1) and torch.equal(_dense(G), dense_of(e, torch.ones(e.size(1))))
+    # TF add_self_loop: unconditional append (sparse_adj.py:58-63)
+    sa = R.SparseAdj(torch.stack([ei[1], ei[0]]), w, [N, N]).add_self_loop(fill_weight=2.0)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev), add_self_loops=True, fill=2.0)
+    A = torch.zeros(N, N, dtype=torch.float64)
+    A.index_put_((sa.row, sa.col), sa.edge_weight.double(), accumulate=True)
+    assert G.nnz == ei.size(1) + N and torch.equal(_dense(G), A)
+    assert (G.eid.cpu() < 0).sum().item() == N
+
+
+def test_gcn_norm_matches_golden_both_flavours(dev, golden):
+    import graphgym_amd as ga
+    z = golden("aggregation.npz")
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        n = int(z[f"{name}/n"])
+        ei = torch.from_numpy(z[f"{name}/edge_index"]).to(dev)
+        w = torch.from_numpy(z[f"{name}/w"]).to(dev)
+        # TF: add loops, degree by row
+        G = ga.CSRGraph.from_edge_index(ei, n, w, add_self_loops=True).gcn_norm("row")
+        ti, tw = z[f"{name}/tf_norm_index"], z[f"{name}/tf_norm_weight"]
+        A = torch.zeros(n, n, dtype=torch.float64)
+        A.index_put_((torch.from_numpy(ti[0]), torch.from_numpy(ti[1])), torch.from_numpy(tw).double(), accumulate=True)
+        close(_dense(G), A, 1e-6)
+        # PyG: remaining loops, degree by source
+        G = ga.CSRGraph.from_edge_index(ei, n, w, remove_self_loops=True, add_self_loops=True,
+                                        keep_loop_weight=True).gcn_norm("col")
+        pi, pw = z[f"{name}/pyg_norm_index"], z[f"{name}/pyg_norm_weight"]
+        if name == "multigraph_selfloop":
+            continue  # two loops on one node: which weight survives is unordered in the reference too
+        A = torch.zeros(n, n, dtype=torch.float64)
+        A.index_put_((torch.from_numpy(pi[1]), torch.from_numpy(pi[0])), torch.from_numpy(pw).double(), accumulate=True)
+        close(_dense(G), A, 1e-6)
+
+
+def test_transpose_and_degree(dev):
+    import graphgym_amd as ga
+    g = torch.Generator().manual_seed(3)
+    N, E = 200, 3000
+    ei = torch.randint(0, N, (2, E), generator=g)
+    w = torch.rand(E, generator=g)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev))
+    T = G.transpose()
+    assert torch.equal(_dense(T), _dense(G).t())
+    assert (T.val.cpu() == G.val.cpu()[T.pos.cpu().long()]).all()
+    A = _dense(G)
+    close(G.degree("row"), A.sum(1), 1e-5)
+    close(G.degree("col"), A.sum(0), 1e-5)
+    assert (G.row_ids().cpu().numpy() == np.repeat(np.arange(N), np.diff(G.rowptr.cpu().numpy()))).all()
+
+
+# --------------------------------------------------------------------------- aggregation
+def test_aggregation_matches_golden(dev, golden):
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    z = golden("aggregation.npz")
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        n = int(z[f"{name}/n"])
+        ei = torch.from_numpy(z[f"{name}/edge_index"]).to(dev)
+        w = torch.from_numpy(z[f"{name}/w"]).to(dev)
+        Gu = ga.CSRGraph.from_edge_index(ei, n)
+        Gw = ga.CSRGraph.from_edge_index(ei, n, w)
+        for d in (1, 3, 64):
+            x = torch.from_numpy(z[f"{name}/x{d}"]).to(dev)
+            for red in ("sum", "mean", "max"):
+                close(ops.spmm(Gu, x, red), z[f"{name}/agg_{red}_d{d}"])
+                close(ops.spmm(Gw, x, red), z[f"{name}/aggw_{red}_d{d}"])
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 63, 64, 96, 100, 128, 130, 256, 260, 512, 1024])
+def test_feature_widths(dev, d):
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(d)
+    N, E = 257, 3000
+    ei = torch.randint(0, N, (2, E), generator=g)
+    w = torch.rand(E, generator=g)
+    x = torch.randn(N, d, generator=g)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev))
+    for red in ("sum", "mean", "max"):
+        close(ops.spmm(G, x.to(dev), red), R.coo_aggregate(ei[1], ei[0], w, x, N, red))
+    # a strided view (leading dimension > d) takes the same path
+    xp = torch.randn(N, d + 4, generator=g)
+    close(ops.spmm(G, xp.to(dev)[:, :d], "sum"), R.coo_aggregate(ei[1], ei[0], w, xp[:, :d], N, "sum"))
+
+
+def test_ragged_edge_cases(dev):
+    """empty graph, single node, all-empty rows (> 64 per segment), hubs split into pieces,
+    duplicates and self loops, a hub as the very last row"""
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(99)
+    cases = []
+    cases.append((4, torch.zeros(2, 0, dtype=torch.int64)))                      # no edges at all
+    cases.append((1, torch.zeros(2, 5, dtype=torch.int64)))                      # one node, 5 self loops
+    cases.append((5000, torch.tensor([[1, 2], [4999, 4999]])))                   # 4998 empty rows then one row
+    hub = torch.stack([torch.randint(0, 300, (9000,), generator=g), torch.full((9000,), 7)])
+    rest = torch.randint(0, 300, (2, 2000), generator=g)
+    cases.append((300, torch.cat([hub, rest], dim=1)))                           # degree 9000 > hub_deg
+    last = torch.stack([torch.randint(0, 50, (5000,), generator=g), torch.full((5000,), 49)])
+    cases.append((50, last))                                                     # hub is the last row
+    two = torch.cat([torch.stack([torch.randint(0, 64, (3000,), generator=g), torch.full((3000,), 10)]),
+                     torch.stack([torch.randint(0, 64, (4000,), generator=g), torch.full((4000,), 11)])], dim=1)
+    cases.append((64, two))                                                      # adjacent hubs
+    for N, ei in cases:
+        E = ei.size(1)
+        w = torch.rand(E, generator=g) + 0.5
+        x = torch.randn(N, 256, generator=g)
+        for ww in (None, w):
+            G = ga.CSRGraph.from_edge_index(ei.to(dev), N, None if ww is None else ww.to(dev))
+            for red in ("sum", "mean", "max"):
+                close(ops.spmm(G, x.to(dev), red), R.coo_aggregate(ei[1], ei[0], ww, x, N, red))
+
+
+def test_plan_covers_every_row_once(dev):
+    """host logic of the segmentation, read back from the device plan"""
+    import graphgym_amd as ga
+    from graphgym_amd import graphgen
+    ei = graphgen.ba_edge_index(20000, 5, seed=4, device=dev)
+    G = ga.CSRGraph.from_edge_index(ei, 20000, add_self_loops=True)
+    plan, counts = G.plan()
+    n_seg, n_hub, n_piece, cap_hub, cap_piece, seg_cost, hub_deg, piece_edges = list(counts)
+    p = plan.cpu().numpy()
+    seg_row = p[16:16 + n_seg + 1]
+    assert seg_row[0] == 0 and seg_row[-1] == 20000 and (np.diff(seg_row) >= 0).all()
+    rowptr = G.rowptr.cpu().numpy()
+    deg = np.diff(rowptr)
+    cost = np.diff(rowptr[seg_row]) + 4 * np.diff(seg_row)
+    nohub = deg.copy(); nohub[deg > hub_deg] = 0
+    assert cost.max() <= seg_cost + nohub.max() + hub_deg + 4     # bounded work per wave (last row may be a hub)
+    assert n_hub == int((deg > hub_deg).sum())
+    hub_row = p[16 + n_seg + 1:16 + n_seg + 1 + n_hub]
+    assert sorted(hub_row.tolist()) == np.nonzero(deg > hub_deg)[0].tolist()
+    assert n_piece == int(np.ceil(deg[deg > hub_deg] / piece_edges).sum())
+
+
+def test_argmax_is_bit_exact_with_ties(dev):
+    import graphgym_amd as ga
+    from graphgym_amd import ops, _lib
+    g = torch.Generator().manual_seed(8)
+    N, E, d = 60, 900, 8
+    ei = torch.randint(0, N, (2, E), generator=g)
+    x = torch.randint(0, 3, (N, d), generator=g).float()             # many ties
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N)
+    y, arg = ops._raw_spmm(G, x.to(dev), _lib.MAX, want_argmax=True)
+    rows = G.row_ids().cpu().long()
+    cols = G.col.cpu().long()
+    ref_arg = R.coo_aggregate_argmax(rows, cols, None, x, N)          # same CSR-sorted entry order
+    assert torch.equal(arg.cpu().long(), ref_arg)
+    close(y, R.coo_aggregate(rows, cols, None, x, N, "max"), 0.0)
+
+
+def test_epilogue_fusion(dev):
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(12)
+    N, E, d = 500, 6000, 128
+    ei = torch.randint(0, N, (2, E), generator=g)
+    x = torch.randn(N, d, generator=g)
+    b = torch.randn(d, generator=g)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N)
+    ref = torch.relu(R.coo_aggregate(ei[1], ei[0], None, x, N, "sum") + 1.25 * x + b)
+    close(ops.spmm(G, x.to(dev), "sum", self_scale=1.25, bias=b.to(dev), relu=True), ref)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
+def test_backward_matches_oracle_autograd(dev, reduce):
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(21)
+    N, E, d = 400, 5000, 96
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :1500] = 3                                                  # a hub row (and, transposed, a hub column)
+    w = torch.rand(E, generator=g) + 0.2
+    x = torch.randn(N, d, generator=g)
+    b = torch.randn(d, generator=g)
+    dy = torch.randn(N, d, generator=g)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev))
+    xg = x.to(dev).requires_grad_(True)
+    bg = b.to(dev).requires_grad_(True)
+    y = ops.spmm(G, xg, reduce, self_scale=0.5, bias=bg, relu=True)
+    y.backward(dy.to(dev))
+    xr = x.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    if reduce == "max":  # route the gradient to the same (CSR-order-first) winner the kernel picks
+        rows, cols = G.row_ids().cpu().long(), G.col.cpu().long()
+        wv = G.val.cpu()
+        agg = R.coo_aggregate(rows, cols, wv, xr, N, "max")
+    else:
+        agg = R.coo_aggregate(ei[1], ei[0], w, xr, N, reduce)
+    yr = torch.relu(agg + 0.5 * xr + br)
+    yr.backward(dy)
+    close(y, yr)
+    close(xg.grad, xr.grad)
+    close(bg.grad, br.grad, 1e-4)
+
+
+def test_two_branch_aggregation(dev):
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(31)
+    N, E, d = 600, 8000, 64
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :2000] = 5
+    w = torch.rand(E, generator=g)
+    x = torch.randn(N, d, generator=g)
+    ids = torch.randperm(N, generator=g)[:40]
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev))
+    xg = x.to(dev).requires_grad_(True)
+    P, Q = ops.idgnn_aggregate(G, ids.to(dev), xg)
+    dP, dQ = torch.randn(N, d, generator=g), torch.randn(N, d, generator=g)
+    (P * dP.to(dev) + Q * dQ.to(dev)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    sel = torch.zeros(N, 1)
+    sel[ids] = 1
+    Pr = R.coo_aggregate(ei[1], ei[0], w, xr, N, "sum")
+    Qr = R.coo_aggregate(ei[1], ei[0], w, xr * sel, N, "sum")
+    (Pr * dP + Qr * dQ).sum().backward()
+    close(P, Pr)
+    close(Q, Qr)
+    close(xg.grad, xr.grad)
+    # rows with no identity neighbour are exactly zero
+    has = torch.zeros(N).index_add_(0, ei[1], sel[ei[0]].view(-1)) > 0
+    assert float(Q.detach().cpu()[~has].abs().max()) == 0.0
+
+
+def test_identity_row_update(dev):
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(41)
+    h = torch.randn(50, 20, generator=g)
+    u = torch.randn(7, 20, generator=g)
+    ids = torch.tensor([3, 9, 0, 49, 17, 21, 8])
+    hg, ug = h.to(dev).requires_grad_(True), u.to(dev).requires_grad_(True)
+    out = ops.index_add_rows(hg, ids.to(dev), ug)
+    close(out, h.index_add(0, ids, u), 0.0)
+    out.sum().backward()
+    assert torch.equal(hg.grad.cpu(), torch.ones(50, 20)) and torch.equal(ug.grad.cpu(), torch.ones(7, 20))
+    xs = ops.gather_rows(hg, ids.to(dev))
+    assert torch.equal(xs.detach().cpu(), h[ids])
+
+
+# --------------------------------------------------------------------------- attention
+def test_attention_pieces(dev):
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(51)
+    N, E, d, H = 120, 1500, 32, 4
+    ei = torch.randint(0, N, (2, E), generator=g)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N, add_self_loops=True)
+    rows, cols = G.row_ids().cpu().long(), G.col.cpu().long()
+    Q, K, V = (torch.randn(N, d, generator=g) for _ in range(3))
+    Qg, Kg, Vg = (t.to(dev).requires_grad_(True) for t in (Q, K, V))
+    s = ops.sddmm_dot(G, Qg, Kg, H, 0.5)
+    p = ops.edge_softmax(G, s)
+    y = ops.spmm_edge_values(G, p, Vg, H)
+    dy = torch.randn(N, d, generator=g)
+    y.backward(dy.to(dev))
+    Qr, Kr, Vr = (t.clone().requires_grad_(True) for t in (Q, K, V))
+    dh = d // H
+    sr = (Qr[rows].view(-1, H, dh) * Kr[cols].view(-1, H, dh)).sum(-1) * 0.5
+    pr = R.softmax(sr, rows, N)
+    yr = torch.zeros(N, H, dh).index_add_(0, rows, pr.unsqueeze(-1) * Vr[cols].view(-1, H, dh)).view(N, d)
+    yr.backward(dy)
+    close(s, sr)
+    close(p, pr)
+    close(y, yr)
+    close(Qg.grad, Qr.grad, 1e-4)
+    close(Kg.grad, Kr.grad, 1e-4)
+    close(Vg.grad, Vr.grad, 1e-4)
+    # additive scores
+    ai, aj = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    aig, ajg = ai.to(dev).requires_grad_(True), aj.to(dev).requires_grad_(True)
+    sa = ops.sddmm_add(G, aig, ajg, 0.2)
+    ds = torch.randn(G.nnz, 1, generator=g)
+    sa.backward(ds.to(dev))
+    air, ajr = ai.clone().requires_grad_(True), aj.clone().requires_grad_(True)
+    sar = torch.nn.functional.leaky_relu(air[rows] + ajr[cols], 0.2).view(-1, 1)
+    sar.backward(ds)
+    close(sa, sar)
+    close(aig.grad, air.grad, 1e-4)
+    close(ajg.grad, ajr.grad, 1e-4)
+
+
+# --------------------------------------------------------------------------- full-size properties
+def test_full_size_properties_c2_and_c4(dev):
+    """BASELINE sizes: C2 (1M nodes / ~11M stored entries) and C4 (10M / ~110M), d = 256.
+    Size-independent checks: ones -> weighted degree, a float64 checksum through the column
+    sums, linearity, and an exact oracle comparison on a random sample of rows."""
+    import graphgym_amd as ga
+    from graphgym_amd import ops, graphgen
+    for n in (1_000_000, 10_000_000):
+        ei = graphgen.ba_edge_index(n, 5, seed=12345, device=dev)
+        G = ga.CSRGraph.from_edge_index(ei, n, add_self_loops=True).gcn_norm("row")
+        del ei
+        d = 256
+        ones = torch.ones(n, d, device=dev)
+        y = ops.spmm(G, ones, "sum")
+        deg = G.degree("row")
+        assert float((y[:, 0] - deg).abs().max()) <= 1e-5 * float(deg.max())
+        assert float((y - y[:, :1]).abs().max()) == 0.0                 # every column identical
+        del ones, y
+        gen = torch.Generator(device=dev).manual_seed(7)
+        x = torch.rand(n, d, device=dev, generator=gen) * 2 - 1
+        y = ops.spmm(G, x, "sum")
+        # checksum of checksums: sum_i y[i,:] == sum_j colsum[j] * x[j,:]
+        lhs = y.double().sum(0)
+        rhs = (G.degree("col").double()[:, None] * x.double()).sum(0)
+        assert float((lhs - rhs).abs().max()) <= 1e-6 * float(rhs.abs().max() + n ** 0.5)
+        # linearity
+        y2 = ops.spmm(G, x * 3.0, "sum")
+        assert float((y2 - 3.0 * y).abs().max()) <= 1e-5 * float(y.abs().max())
+        del y2
+        # oracle on a sample of rows (gathered from the CSR itself)
+        rows = torch.randint(0, n, (512,), device=dev, generator=gen)
+        rows = torch.cat([rows, torch.arange(0, 8, device=dev)])        # the hubs too
+        rp = G.rowptr.long()
+        for r in rows.tolist():
+            s, e = int(rp[r]), int(rp[r + 1])
+            ref = (G.val[s:e, None].cpu() * x[G.col[s:e].long()].cpu())
+            ref = torch.zeros(1, d).index_add_(0, torch.zeros(e - s, dtype=torch.int64), ref)
+            close(y[r:r + 1], ref)
+        del x, y, G
+        torch.cuda.empty_cache()
