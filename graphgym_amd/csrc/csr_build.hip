@@ -184,8 +184,18 @@ __global__ __launch_bounds__(kBlock) void degree_row_kernel(const int32_t* __res
        r += (int64_t)gridDim.x * blockDim.x) {
     const int s = rowptr[r], e = rowptr[r + 1];
     float acc = 0.f;
-    if (val) { for (int k = s; k < e; ++k) acc += val[k]; }
-    else acc = (float)(e - s);
+    if (val) {
+      // compensated (Kahan) sum: hub rows add 10^4 terms, a plain fp32 running sum drifts ~1e-4 relative
+      float comp = 0.f;
+      for (int k = s; k < e; ++k) {
+        const float yv = val[k] - comp;
+        const float t = acc + yv;
+        comp = (t - acc) - yv;
+        acc = t;
+      }
+    } else {
+      acc = (float)(e - s);
+    }
     deg[r] = acc;
   }
 }

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 passes of scripts/prof_run.sh into the committed evidence under profiles/.
+
+    python scripts/summarize_prof.py gpurun_out/prof_r01 r01 <workload-tag>
+
+Writes profiles/<tag>_kernel_stats.csv (the --kernel-trace --stats summary, engine kernels only),
+profiles/<tag>_pmc.json (FETCH_SIZE / WRITE_SIZE per launch of the aggregation kernel) and
+profiles/pmc_traffic.json (what bench.py reports as roofline.traffic).
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: counters are in KiB; on gfx950
+FETCH_SIZE reads exactly 1/2 of a wide (16 B/lane) coalesced read stream, so it is doubled;
+WRITE_SIZE is exact for 16-B-per-lane streaming stores.  The two counters come from separate passes.
+"""
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+src, tag, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
+
+rows = []
+for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
+    for r in csv.DictReader(open(f)):
+        if "mp::" in r["Name"]:
+            rows.append(r)
+with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    w.writeheader()
+    w.writerows(rows)
+
+pmc = {}
+for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    for f in glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter or "mp::agg_" not in r["Kernel_Name"]:
+                continue
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            pmc.setdefault(k, {}).setdefault(counter, []).append(
+                (float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+summary = {}
+for k, d in pmc.items():
+    e = {}
+    for counter, vals in d.items():
+        e[counter + "_KiB_median"] = statistics.median(v for v, _ in vals)
+        e[counter + "_launches"] = len(vals)
+        e[counter + "_pass_duration_ns_median"] = statistics.median(t for _, t in vals)
+    summary[k] = e
+main = next(k for k in summary if "agg_rows_kernel" in k)
+fetch = summary[main]["FETCH_SIZE_KiB_median"] * 1024 * 2     # gfx950: wide coalesced reads are tallied at 1/2
+write = summary[main]["WRITE_SIZE_KiB_median"] * 1024
+rec = {"workload": workload, "kernel": main, "fetch_bytes_corrected": fetch, "write_bytes": write,
+       "hbm_bytes_per_launch": fetch + write,
+       "note": "FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md §HBM), KiB units, separate --pmc passes; "
+               "counters sit on the L2's fabric side, so Infinity-Cache hits are included",
+       "per_kernel": summary}
+json.dump(rec, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
+json.dump({"workload": workload, "hbm_bytes_per_launch": fetch + write, "source": f"profiles/{tag}_pmc.json"},
+          open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(rec, indent=1)[:1200])
