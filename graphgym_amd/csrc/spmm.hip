@@ -49,6 +49,19 @@ template <> __device__ __forceinline__ void store_vec<2>(float* p, const float (
 }
 template <> __device__ __forceinline__ void store_vec<1>(float* p, const float (&v)[1]) { *p = v[0]; }
 
+// streaming (non-temporal) store of an output row: written once, never re-read by this kernel
+template <int W> __device__ __forceinline__ void store_vec_nt(float* p, const float (&v)[W]) {
+  if constexpr (W == 4) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+  } else if constexpr (W == 2) {
+    f32x2 t = {v[0], v[1]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x2*>(p));
+  } else {
+    __builtin_nontemporal_store(v[0], p);
+  }
+}
+
 template <int W> __device__ __forceinline__ void store_ivec(int32_t* p, const int (&v)[W]);
 template <> __device__ __forceinline__ void store_ivec<4>(int32_t* p, const int (&v)[4]) {
   i32x4 t = {v[0], v[1], v[2], v[3]};
@@ -143,7 +156,7 @@ struct RowAcc {
 };
 
 // Epilogue + store of one finished output row (K15/K17 fused into the flush).
-template <int W, int REDUCE, bool BRANCH2>
+template <int W, int REDUCE, bool BRANCH2, bool NT = false>
 __device__ __forceinline__ void finish_row(const AggArgs& a, int row, int deg,
                                            RowAcc<W, REDUCE, BRANCH2>& acc,
                                            int c0, int c0ld, bool lane_on) {
@@ -171,7 +184,8 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int row, int deg,
     for (int k = 0; k < W; ++k) out[k] = fmaxf(out[k], 0.f);
   }
   if (lane_on) {
-    store_vec<W>(a.Y + (int64_t)row * a.ldy + c0, out);
+    if constexpr (NT) store_vec_nt<W>(a.Y + (int64_t)row * a.ldy + c0, out);
+    else store_vec<W>(a.Y + (int64_t)row * a.ldy + c0, out);
     if constexpr (BRANCH2) store_vec<W>(a.Q + (int64_t)row * a.ldq + c0, acc.b);
     if constexpr (REDUCE == MP_MAX) {
       if (a.argmax != nullptr) store_ivec<W>(a.argmax + (int64_t)row * a.d + c0, acc.arg);
@@ -181,8 +195,13 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int row, int deg,
 }
 
 // Main kernel: one wave per segment of whole rows.
-template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2, int U>
+// VAR bits (tuning experiments, mp_spmm_kernel_config): 1 = non-temporal stores of Y,
+// 2 = non-temporal loads of the index / value streams, 4 = prefetch the next 64 indices
+template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2, int U, int VAR = 0>
 __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
+  constexpr bool NT_ST = VAR & 1;
+  constexpr bool NT_IDX = VAR & 2;
+  constexpr bool PREF = VAR & 4;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int seg = blockIdx.x * kWavesPerBlock + wave;
@@ -225,11 +244,26 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
     rend = (r < r1) ? bcast_i(rendv, r - rbase) : INT_MAX;
   };
 
-  for (int ec = e0; ec < e1; ec += kWave) {
+  auto load_idx = [&](int ec, int& cv, float& wv) {
     const int me = min(ec + lane, e1 - 1);
-    const int cv = a.col[me];
-    float wv = 1.f;
-    if (WEIGHTED) wv = a.val[me];
+    if constexpr (NT_IDX) {
+      cv = __builtin_nontemporal_load(a.col + me);
+      if (WEIGHTED) wv = __builtin_nontemporal_load(a.val + me);
+    } else {
+      cv = a.col[me];
+      if (WEIGHTED) wv = a.val[me];
+    }
+  };
+  int cv = 0, cvn = 0;
+  float wv = 1.f, wvn = 1.f;
+  if constexpr (PREF) load_idx(e0, cvn, wvn);
+  for (int ec = e0; ec < e1; ec += kWave) {
+    if constexpr (PREF) {
+      cv = cvn; wv = wvn;
+      if (ec + kWave < e1) load_idx(ec + kWave, cvn, wvn);
+    } else {
+      load_idx(ec, cv, wv);
+    }
     const int n = min(kWave, e1 - ec);
     for (int jb = 0; jb < n; jb += U) {
       float v[U][W];
@@ -245,7 +279,7 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
         const int e = ec + jb + j;
         if (e < e1) {
           while (e >= rend) {
-            finish_row<W, REDUCE, BRANCH2>(a, r, rend - rstart, acc, c0, c0ld, lane_on);
+            finish_row<W, REDUCE, BRANCH2, NT_ST>(a, r, rend - rstart, acc, c0, c0ld, lane_on);
             advance();
           }
           const float w = WEIGHTED ? bcast_f(wv, jb + j) : 1.f;
@@ -255,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
     }
   }
   while (r < r1) {
-    finish_row<W, REDUCE, BRANCH2>(a, r, rend - rstart, acc, c0, c0ld, lane_on);
+    finish_row<W, REDUCE, BRANCH2, NT_ST>(a, r, rend - rstart, acc, c0, c0ld, lane_on);
     advance();
   }
 }
@@ -454,12 +488,29 @@ __global__ __launch_bounds__(kBlock) void plan_hub_kernel(const int32_t* __restr
 
 // ---- dispatch -------------------------------------------------------------
 
+static int g_unroll = 8;   // rows in flight per wave (4, 8, 16)
+static int g_var = 0;      // VAR bits of agg_rows_kernel
+
 template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2>
 static int launch_agg(const AggArgs& a, int64_t N, const int32_t* counts, hipStream_t st) {
   constexpr int U = 8;
   const int tiles = (int)ceil_div(a.d, kWave * W);
   dim3 grid((unsigned)ceil_div(a.n_seg, kWavesPerBlock), (unsigned)tiles);
-  hipLaunchKernelGGL((agg_rows_kernel<W, REDUCE, WEIGHTED, BRANCH2, U>), grid, dim3(kBlock), 0, st, a);
+  bool launched = false;
+  if constexpr (W == 4 && REDUCE == MP_SUM && WEIGHTED && !BRANCH2) {
+    // tuning variants exist for the headline instantiation only (mp_spmm_kernel_config)
+#define MP_VARIANT(UU, VV)                                                                          \
+    if (!launched && g_unroll == UU && g_var == VV) {                                               \
+      hipLaunchKernelGGL((agg_rows_kernel<W, REDUCE, WEIGHTED, BRANCH2, UU, VV>), grid, dim3(kBlock), \
+                         0, st, a);                                                                 \
+      launched = true;                                                                              \
+    }
+    MP_VARIANT(4, 0) MP_VARIANT(16, 0) MP_VARIANT(8, 1) MP_VARIANT(8, 2) MP_VARIANT(8, 3)
+    MP_VARIANT(8, 4) MP_VARIANT(8, 5) MP_VARIANT(8, 7) MP_VARIANT(16, 7) MP_VARIANT(16, 1) MP_VARIANT(4, 7)
+#undef MP_VARIANT
+  }
+  if (!launched)
+    hipLaunchKernelGGL((agg_rows_kernel<W, REDUCE, WEIGHTED, BRANCH2, U>), grid, dim3(kBlock), 0, st, a);
   MP_LAUNCH_CHECK();
   const int n_hub = counts[1], n_piece = counts[2];
   if (n_hub > 0) {
@@ -604,6 +655,14 @@ extern "C" {
 int mp_spmm_plan_config(int seg_cost, int row_cost, int hub_deg, int piece_edges) {
   if (seg_cost < 64 || row_cost < 0 || hub_deg < seg_cost || piece_edges < 64) return MP_ERR_INVALID_ARG;
   g_cfg = {seg_cost, row_cost, hub_deg, piece_edges};
+  return MP_OK;
+}
+
+int mp_spmm_kernel_config(int rows_in_flight, int variant_bits) {
+  if (rows_in_flight != 4 && rows_in_flight != 8 && rows_in_flight != 16) return MP_ERR_INVALID_ARG;
+  if (variant_bits < 0 || variant_bits > 7) return MP_ERR_INVALID_ARG;
+  g_unroll = rows_in_flight;
+  g_var = variant_bits;
   return MP_OK;
 }
 
