@@ -90,7 +90,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", torch.cuda.current_device())
 
     n, d = args.nodes, args.d
     ei = graphgen.ba_edge_index(n, args.m, seed=12345 + rank, device=dev)

@@ -57,6 +57,9 @@ PROTOTYPES = {
     "mp_csr_row_softmax_bwd_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     "mp_sddmm_grad_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _p]),
     "mp_spmm_heads_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _p]),
+    "mp_ego_ws_bytes": (C.c_int, [_i64, _i64, _psz]),
+    "mp_ego_expand_count": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _sz, _p, _p]),
+    "mp_ego_expand_emit": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _sz, _p, _p, _p, _p, _p]),
     "mp_gen_ba_edges_host": (C.c_int, [_i64, _i32, C.c_uint64, _p, _p, _p]),
 }
 

@@ -36,12 +36,22 @@ def init_from_env(device_type=None):
     if device_type is None:
         device_type = "cuda" if torch.cuda.is_available() else "cpu"
     if device_type == "cuda":
+        if os.environ.get("MP_SHARE_DEVICE") == "1":      # rehearsal of N ranks on a 1-GPU box (gloo only)
+            local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl" if device_type == "cuda" else "gloo", rank=rank, world_size=world)
+        backend = os.environ.get("MP_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def _coll_device(device):
+    """collectives on scalars run on the GPU under RCCL and on the host under gloo"""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return device
 
 
 def barrier():
@@ -50,14 +60,14 @@ def barrier():
 
 
 def all_reduce_max(value, device):
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def all_reduce_sum(value, device):
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
@@ -89,7 +99,12 @@ class GradBucket:
                 v.zero_()
             else:
                 v.copy_(p.grad)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if dist.get_backend() == "gloo" and self.flat.is_cuda:   # rehearsal mode: stage through the host
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(dist.get_world_size())
         for p, v in zip(self.params, self.views):
             if p.grad is None:

@@ -146,7 +146,7 @@ int mp_mark_id_sources(const int32_t* col, int64_t nnz, const int64_t* id_index,
 int mp_spmm_plan_config(int seg_cost, int row_cost, int hub_deg, int piece_edges);
 /* tuning knobs of the hot kernel's headline instantiation (fp32 x4, weighted sum); other
  * instantiations ignore them.  rows_in_flight in {4, 8, 16}; variant_bits: 1 = non-temporal
- * stores of Y, 2 = non-temporal index loads, 4 = prefetch of the next index tile.  Default 8, 0. */
+ * stores of Y, 2 = non-temporal index loads, 4 = prefetch of the next index tile.  Default 8, 1. */
 int mp_spmm_kernel_config(int rows_in_flight, int variant_bits);
 int mp_spmm_plan_bytes(int64_t N, int64_t nnz, size_t* bytes_host);
 /* counts_host[8] <- {n_seg, n_hub, n_piece, cap_hub, cap_piece, seg_cost, hub_deg,
@@ -244,6 +244,28 @@ int mp_sddmm_grad_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int6
 int mp_spmm_heads_f32(const int32_t* rowptr, const int32_t* col, const float* a,
                       int64_t N, int32_t heads, const float* V, int64_t ldv,
                       float* Y, int64_t ldy, int32_t d, mp_stream_t stream);
+
+/* ------------------------------------------------------------------ *
+ * Ego-net batcher: graphgym/models/transform.py:11-38 *
+ * for a batch of centre nodes, on the device.  The base CSR must be    *
+ * symmetric (the reference's graphs are undirected nx.Graph).          *
+ *   new ids: centre c -> c (0..B-1); other members of ego c -> fresh    *
+ *   consecutive ids in ascending original id, egos one after another;   *
+ *   radius > 4 takes the whole graph (transform.py:18-19).              *
+ * Two calls: _count sizes the outputs (SYNCHRONISES), _emit fills them  *
+ * from the same workspace.                                              *
+ * ------------------------------------------------------------------ */
+int mp_ego_ws_bytes(int64_t N, int64_t n_centres, size_t* bytes_host);
+/* counts_host[2] <- {total nodes of the expanded graph, total directed edges} */
+int mp_ego_expand_count(const int32_t* rowptr, const int32_t* col, int64_t N,
+                        const int64_t* centres, int64_t n_centres, int32_t radius,
+                        void* ws, size_t ws_bytes, int64_t* counts_host, mp_stream_t stream);
+/* out_src/out_dst [edges] int64 (new ids, unordered within an ego), orig_node [nodes] int64
+ * (original id of every new node), ego_of_node [nodes] int32 or NULL (owning centre) */
+int mp_ego_expand_emit(const int32_t* rowptr, const int32_t* col, int64_t N,
+                       const int64_t* centres, int64_t n_centres, void* ws, size_t ws_bytes,
+                       int64_t* out_src, int64_t* out_dst, int64_t* orig_node,
+                       int32_t* ego_of_node, mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * Host-side synthetic graph generator (bench / tests; not a device op) *
