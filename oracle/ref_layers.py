@@ -271,23 +271,35 @@ def pyg_gin_conv(x, edge_index, nn_fn, eps=0.0):
 
 
 # ------------------------ ego-net expansion (K-next) ------------------------ #
-def ego_nets(G, radius=2):
+def ego_nets(G, radius=2, return_map=False):
     """graphgym/models/transform.py:11-38 on a networkx graph with nodes 0..n-1.
-    Returns (G_ego, node_id_index): centres keep ids 0..n-1, other ego members get fresh ids."""
+    Returns (G_ego, node_id_index): centres keep ids 0..n-1, other ego members get fresh ids.
+    The order of the fresh ids inside one ego is whatever order networkx iterates the ego's node
+    set in (a Python set for small egos), i.e. implementation-defined; with return_map=True the
+    function also returns (orig, ego_of): original id and owning centre of every new node, so that
+    callers can compare expansions up to that relabelling."""
     import networkx as nx
     n = G.number_of_nodes()
     egos = [G if radius > 4 else nx.ego_graph(G, i, radius=radius) for i in range(n)]
     H = G.__class__()
     id_bias = n
+    orig, ego_of = {}, {}
     for i in range(n):
         H.add_node(i, **egos[i].nodes(data=True)[i])
+        orig[i], ego_of[i] = i, i
     for i in range(n):
         keys = list(egos[i].nodes)
         keys.remove(i)
         id_cur = egos[i].number_of_nodes() - 1
         mapping = dict(zip(keys, range(id_bias, id_bias + id_cur)))
         id_bias += id_cur
+        for k, v in mapping.items():
+            orig[v], ego_of[v] = k, i
         ego = nx.relabel_nodes(egos[i], mapping, copy=True)
         H.add_nodes_from(ego.nodes(data=True))
         H.add_edges_from(ego.edges(data=True))
+    if return_map:
+        N = H.number_of_nodes()
+        return (H, torch.arange(n), torch.tensor([orig[k] for k in range(N)]),
+                torch.tensor([ego_of[k] for k in range(N)]))
     return H, torch.arange(n)

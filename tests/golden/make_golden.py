@@ -75,17 +75,21 @@ def gen_aggregation():
     return len(rec)
 
 
-def ego_batch(n=12, m=2, radius=2, seed=7):
+def ego_batch(n=12, m=2, radius=2, seed=7, with_map=False):
     G = nx.powerlaw_cluster_graph(n, m, 0.3, seed=seed)
-    H, ids = RL.ego_nets(G, radius)
+    H, ids, orig, ego_of = RL.ego_nets(G, radius, return_map=True)
+    if with_map:
+        return H.number_of_nodes(), directed(H), ids.numpy(), directed(G), orig.numpy(), ego_of.numpy()
     return H.number_of_nodes(), directed(H), ids.numpy(), directed(G)
 
 
 def gen_ego():
     """transform.py:11-38 on small synthetic graphs: expanded edge list + id index"""
     rec = {}
-    for k, (n, m, radius) in enumerate([(12, 2, 2), (16, 3, 3), (10, 2, 5)]):
-        N, ei, ids, base = ego_batch(n, m, radius, seed=11 + k)
+    for k, (n, m, radius) in enumerate([(12, 2, 2), (16, 3, 3), (10, 2, 5), (40, 2, 1)]):
+        N, ei, ids, base, orig, ego_of = ego_batch(n, m, radius, seed=11 + k, with_map=True)
+        rec[f"g{k}/orig_node"] = orig
+        rec[f"g{k}/ego_of_node"] = ego_of
         rec[f"g{k}/base_n"] = np.int64(n)
         rec[f"g{k}/radius"] = np.int64(radius)
         rec[f"g{k}/base_edge_index"] = base

@@ -23,38 +23,47 @@ def expand_on_gpu(dev, base_ei, n, radius, centres=None):
     return ego_batch(base, cen, radius)
 
 
+def canon(ei, orig, ego_of):
+    """expansion up to the relabelling inside each ego: {(centre, original u, original v)}"""
+    ei, orig, ego_of = np.asarray(ei), np.asarray(orig), np.asarray(ego_of)
+    assert (ego_of[ei[0]] == ego_of[ei[1]]).all()              # egos are disjoint components
+    return set(zip(ego_of[ei[0]].tolist(), orig[ei[0]].tolist(), orig[ei[1]].tolist()))
+
+
 def test_matches_committed_golden(dev, golden):
     z = golden("ego.npz")
-    for k in range(3):
+    for k in range(4):
         n, radius = int(z[f"g{k}/base_n"]), int(z[f"g{k}/radius"])
         ei, orig, ids, ego_of = expand_on_gpu(dev, z[f"g{k}/base_edge_index"], n, radius)
         assert orig.numel() == int(z[f"g{k}/ego_n"])
         assert ids.cpu().tolist() == z[f"g{k}/node_id_index"].tolist()
         ref = z[f"g{k}/ego_edge_index"]
-        got = set(map(tuple, ei.t().cpu().tolist()))
-        want = set(map(tuple, ref.T.tolist()))
-        assert got == want and ei.size(1) == ref.shape[1]      # same new ids, same induced edges
+        assert ei.size(1) == ref.shape[1]
+        assert canon(ei.cpu().numpy(), orig.cpu().numpy(), ego_of.cpu().numpy()) == \
+            canon(ref, z[f"g{k}/orig_node"], z[f"g{k}/ego_of_node"])
         assert orig[:n].cpu().tolist() == list(range(n))        # centres keep their ids
+        # the sizes of the egos, hence the first fresh id of each, are bit-exact
+        assert np.array_equal(np.bincount(ego_of.cpu().numpy()), np.bincount(z[f"g{k}/ego_of_node"]))
 
 
 @pytest.mark.parametrize("radius", [1, 2, 3, 5])
 def test_against_networkx_restatement(dev, radius):
     G = nx.powerlaw_cluster_graph(40, 2, 0.3, seed=radius)
     G.add_edge(3, 3)                                            # a self loop survives the induced subgraph
-    H, ids = RL.ego_nets(G, radius)
+    H, ids, h_orig, h_ego = RL.ego_nets(G, radius, return_map=True)
     ei, orig, idx, ego_of = expand_on_gpu(dev, directed(G), 40, radius)
     assert orig.numel() == H.number_of_nodes()
-    got = set(map(tuple, ei.t().cpu().tolist()))
-    want = set()
-    for u, v in H.edges():
-        want.add((u, v)); want.add((v, u))
-    assert got == want
+    hd = directed(H)
+    assert canon(ei.cpu().numpy(), orig.cpu().numpy(), ego_of.cpu().numpy()) == \
+        canon(hd, h_orig.numpy(), h_ego.numpy())
     # orig maps fresh ids back: members of ego c are exactly nx.ego_graph(G, c, radius)
     orig_c, ego_c = orig.cpu().numpy(), ego_of.cpu().numpy()
     for c in range(40):
         members = set(orig_c[ego_c == c].tolist())
         want_m = set(G.nodes) if radius > 4 else set(nx.ego_graph(G, c, radius=radius).nodes)
         assert members == want_m
+        fresh = orig_c[40:][ego_c[40:] == c]
+        assert (np.diff(fresh) > 0).all()                       # our fresh ids ascend with the original id
 
 
 def test_subset_of_centres_on_a_large_graph(dev):
