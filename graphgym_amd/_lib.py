@@ -35,7 +35,7 @@ PROTOTYPES = {
     "mp_check_edge_index": (C.c_int, [_p, _p, _i64, _i64, _p, _p]),
     "mp_csr_row_ids": (C.c_int, [_p, _i64, _i64, _p, _p]),
     "mp_csr_transpose_ws_bytes": (C.c_int, [_i64, _i64, _psz]),
-    "mp_csr_transpose": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "mp_csr_transpose": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mp_csr_degree": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _p, _p]),
     "mp_gcn_norm_edges": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _p, _p, _p]),
     "mp_mark_id_sources": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _p, _p]),

@@ -367,12 +367,14 @@ int mp_csr_transpose_ws_bytes(int64_t nnz, int64_t N, size_t* bytes_host) {
   return MP_OK;
 }
 
-int mp_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int64_t nnz,
-                     int32_t* t_rowptr, int32_t* t_col, float* t_val, int32_t* pos, void* ws,
-                     size_t ws_bytes, mp_stream_t stream) {
-  if (!rowptr || !t_rowptr || N < 0 || nnz < 0 || (nnz > 0 && (!col || !t_col))) return MP_ERR_INVALID_ARG;
-  if (nnz >= INT32_MAX) return MP_ERR_UNSUPPORTED;
+int mp_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                     int64_t n_cols, int64_t nnz, int32_t* t_rowptr, int32_t* t_col, float* t_val,
+                     int32_t* pos, void* ws, size_t ws_bytes, mp_stream_t stream) {
+  if (!rowptr || !t_rowptr || n_rows < 0 || n_cols < 0 || nnz < 0 || (nnz > 0 && (!col || !t_col)))
+    return MP_ERR_INVALID_ARG;
+  if (nnz >= INT32_MAX || n_rows >= INT32_MAX || n_cols >= INT32_MAX) return MP_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
+  const int64_t N = n_cols;   // the transpose has one row per column of the source
   if (nnz == 0) {
     MP_HIP(hipMemsetAsync(t_rowptr, 0, (size_t)(N + 1) * 4, st));
     return MP_OK;
@@ -382,7 +384,7 @@ int mp_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val
   if (rc != MP_OK) return rc;
   if (!ws || ws_bytes < L.total) return MP_ERR_WORKSPACE;
   hipLaunchKernelGGL(transpose_keys_kernel, dim3(flat_grid(nnz)), dim3(kBlock), 0, st, rowptr, col,
-                     (int32_t)N, nnz, L.keys_a, L.pay_a);
+                     (int32_t)n_rows, nnz, L.keys_a, L.pay_a);
   MP_LAUNCH_CHECK();
   hipcub::DoubleBuffer<uint64_t> dk(L.keys_a, L.keys_b);
   hipcub::DoubleBuffer<uint32_t> dv(L.pay_a, L.pay_b);

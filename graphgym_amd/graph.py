@@ -28,7 +28,8 @@ def _require_hip(t, name):
 
 
 class CSRGraph:
-    def __init__(self, rowptr, col, val, eid, num_nodes, nnz):
+    def __init__(self, rowptr, col, val, eid, num_nodes, nnz, num_cols=None):
+        self.num_cols = int(num_nodes if num_cols is None else num_cols)   # != num_nodes for pooling operators
         self.rowptr = rowptr      # [N+1] int32
         self.col = col            # [nnz] int32 (view of a capacity-sized buffer)
         self.val = val            # [nnz] fp32 or None (= ones)
@@ -97,7 +98,7 @@ class CSRGraph:
 
     def with_values(self, val):
         """same sparsity pattern (and plan / transpose pattern), other entry values"""
-        g = CSRGraph(self.rowptr, self.col, val, self.eid, self.num_nodes, self.nnz)
+        g = CSRGraph(self.rowptr, self.col, val, self.eid, self.num_nodes, self.nnz, self.num_cols)
         g._plan = self._plan
         return g
 
@@ -124,7 +125,7 @@ class CSRGraph:
         """CSR of A^T (rows = sources) with values permuted; cached."""
         if self._t is None:
             L = lib()
-            N, nnz, dev = self.num_nodes, self.nnz, self.device
+            R, N, nnz, dev = self.num_nodes, self.num_cols, self.nnz, self.device
             with torch.cuda.device(dev):
                 nb = C.c_size_t(0)
                 check(L.mp_csr_transpose_ws_bytes(nnz, N, C.byref(nb)))
@@ -133,10 +134,10 @@ class CSRGraph:
                 t_col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
                 t_val = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev) if self.val is not None else None
                 pos = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
-                check(L.mp_csr_transpose(ptr(self.rowptr), ptr(self.col), ptr(self.val), N, nnz,
+                check(L.mp_csr_transpose(ptr(self.rowptr), ptr(self.col), ptr(self.val), R, N, nnz,
                                          ptr(t_rowptr), ptr(t_col), ptr(t_val), ptr(pos), ptr(ws),
                                          nb.value, _stream()), "mp_csr_transpose")
-            t = CSRGraph(t_rowptr, t_col[:nnz], None if t_val is None else t_val[:nnz], None, N, nnz)
+            t = CSRGraph(t_rowptr, t_col[:nnz], None if t_val is None else t_val[:nnz], None, N, nnz, R)
             t.pos = pos[:nnz]
             self._t = t
         return self._t
@@ -145,7 +146,7 @@ class CSRGraph:
         """transpose pattern of this graph carrying other per-entry values"""
         t = self.transpose()
         g = CSRGraph(t.rowptr, t.col, val[t.pos.long()] if val is not None else None, None,
-                     t.num_nodes, t.nnz)
+                     t.num_nodes, t.nnz, t.num_cols)
         g._plan = t._plan
         g.pos = t.pos
         return g

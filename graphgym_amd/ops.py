@@ -47,8 +47,8 @@ class _SpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias, g, reduce, self_scale, relu):
         x = _f32c(x, "x")
-        if x.size(0) != g.num_nodes:
-            raise ValueError(f"x has {x.size(0)} rows, graph has {g.num_nodes} nodes")
+        if x.size(0) != g.num_cols:
+            raise ValueError(f"x has {x.size(0)} rows, the operator has {g.num_cols} columns")
         S = x if self_scale != 0.0 else None
         b = None if bias is None else bias.detach().contiguous()
         y, argmax = _raw_spmm(g, x, reduce, S=S, self_scale=self_scale, bias=b, relu=relu,
@@ -78,7 +78,7 @@ class _SpMM(torch.autograd.Function):
             else:
                 L = lib()
                 N, d = dy.shape
-                dx = torch.zeros((g.num_nodes, d), dtype=torch.float32, device=dy.device)
+                dx = torch.zeros((g.num_cols, d), dtype=torch.float32, device=dy.device)
                 with torch.cuda.device(dy.device):
                     check(L.mp_spmm_max_bwd_f32(ptr(g.col), ptr(g.val), ptr(argmax), ptr(dy), dy.stride(0),
                                                 N, d, ptr(dx), dx.stride(0), _stream()), "mp_spmm_max_bwd_f32")

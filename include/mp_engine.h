@@ -108,9 +108,11 @@ int mp_csr_row_ids(const int32_t* rowptr, int64_t N, int64_t nnz,
  * pos[k] = index in the source CSR of transposed entry k (so per-edge values
  * such as attention coefficients can be permuted with one gather).
  */
+/* n_rows x n_cols source (square graphs: both N; pooling operators are rectangular);
+ * the workspace query takes N = n_cols */
 int mp_csr_transpose_ws_bytes(int64_t nnz, int64_t N, size_t* bytes_host);
 int mp_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val,
-                     int64_t N, int64_t nnz,
+                     int64_t n_rows, int64_t n_cols, int64_t nnz,
                      int32_t* t_rowptr, int32_t* t_col, float* t_val, int32_t* pos,
                      void* ws, size_t ws_bytes, mp_stream_t stream);
 
