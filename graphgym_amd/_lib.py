@@ -46,6 +46,8 @@ PROTOTYPES = {
     "mp_spmm_ws_bytes": (C.c_int, [_pi32, _i32, C.c_int, C.c_int, _psz]),
     "mp_spmm_csr_f32": (C.c_int, [_p, _p, _p, _i64, _p, _pi32, _p, _i64, _p, _i64, _i32, C.c_int,
                                   _p, _i64, _f32, _p, C.c_int, _p, _p, _sz, _p]),
+    "mp_spmm_csr_epilogue_f32": (C.c_int, [_p, _p, _p, _i64, _p, _pi32, _p, _i64, _p, _i64, _i32, C.c_int,
+                                           _p, _i64, _f32, _p, _p, C.c_int, C.c_int, _f32, _p, _sz, _p]),
     "mp_idgnn_agg_f32": (C.c_int, [_p, _p, _p, _i64, _p, _pi32, _p, _i64, _p, _i64, _p, _i64, _i32,
                                    _p, _sz, _p]),
     "mp_spmm_max_bwd_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _i64, _p]),

@@ -104,7 +104,10 @@ struct AggArgs {
   float* Q; int64_t ldq;
   const float* S; int64_t lds; float self_scale;
   const float* bias;
+  const float* col_scale;   // per-column multiplier applied before bias (BatchNorm in eval mode folded)
   int32_t act;
+  int32_t l2norm;           // normalise the finished row to unit L2 norm (single column tile only)
+  float l2_eps;
   int32_t* argmax;
   int32_t d;
   // hub path
@@ -173,6 +176,12 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int row, int deg,
 #pragma unroll
     for (int k = 0; k < W; ++k) out[k] = fmaf(a.self_scale, s[k], out[k]);
   }
+  if (a.col_scale != nullptr) {
+    float sv[W];
+    load_vec<W>(a.col_scale + c0ld, sv);
+#pragma unroll
+    for (int k = 0; k < W; ++k) out[k] *= sv[k];
+  }
   if (a.bias != nullptr) {
     float bv[W];
     load_vec<W>(a.bias + c0ld, bv);
@@ -182,6 +191,18 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int row, int deg,
   if (a.act == MP_ACT_RELU) {
 #pragma unroll
     for (int k = 0; k < W; ++k) out[k] = fmaxf(out[k], 0.f);
+  }
+  if (a.l2norm) {
+    // F.normalize(p=2, dim=-1) (layer.py:43-46, gnn.py:79-80): the wave holds the whole row
+    float ss = 0.f;
+    if (lane_on) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) ss = fmaf(out[k], out[k], ss);
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, kWave);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), a.l2_eps);
+#pragma unroll
+    for (int k = 0; k < W; ++k) out[k] *= inv;
   }
   if (lane_on) {
     if constexpr (NT) store_vec_nt<W>(a.Y + (int64_t)row * a.ldy + c0, out);
@@ -562,7 +583,8 @@ static int pick_width(const AggArgs& a) {
     if (a.Q && a.ldq % w) return false;
     if (a.S && a.lds % w) return false;
     return aligned(a.X, bytes) && aligned(a.Y, bytes) && aligned(a.Q, bytes) &&
-           aligned(a.S, bytes) && aligned(a.bias, bytes) && aligned(a.argmax, bytes) &&
+           aligned(a.S, bytes) && aligned(a.bias, bytes) && aligned(a.col_scale, bytes) &&
+           aligned(a.argmax, bytes) &&
            aligned(a.part, bytes) && aligned(a.part2, bytes) && aligned(a.part_arg, bytes);
   };
   int w = 4;
@@ -575,7 +597,8 @@ static int agg_common(const int32_t* rowptr, const int32_t* col, const float* va
                       const int32_t* plan, const int32_t* counts, const float* X, int64_t ldx,
                       float* Y, int64_t ldy, float* Q, int64_t ldq, int32_t d, int reduce,
                       const float* S, int64_t lds, float self_scale, const float* bias, int act,
-                      int32_t* argmax, void* ws, size_t ws_bytes, hipStream_t st) {
+                      int32_t* argmax, void* ws, size_t ws_bytes, hipStream_t st,
+                      const float* col_scale = nullptr, int l2norm = 0, float l2_eps = 1e-12f) {
   if (!rowptr || !plan || !counts || !X || !Y) return MP_ERR_INVALID_ARG;
   if (N < 0 || d <= 0 || ldx < d || ldy < d) return MP_ERR_INVALID_ARG;
   if (reduce < MP_SUM || reduce > MP_MAX) return MP_ERR_INVALID_ARG;
@@ -601,6 +624,7 @@ static int agg_common(const int32_t* rowptr, const int32_t* col, const float* va
   a.piece_edges = counts[7];
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.Q = Q; a.ldq = ldq;
   a.S = S; a.lds = lds; a.self_scale = self_scale; a.bias = bias; a.act = act;
+  a.col_scale = col_scale; a.l2norm = l2norm; a.l2_eps = l2_eps;
   a.argmax = argmax; a.d = d;
   a.hub_row = a.hub_base = a.hub_np = a.piece_hub = a.piece_k = nullptr;
   a.part = a.part2 = nullptr; a.part_arg = nullptr;
@@ -620,6 +644,7 @@ static int agg_common(const int32_t* rowptr, const int32_t* col, const float* va
   }
 
   const int w = pick_width(a);
+  if (l2norm && d > kWave * w) return MP_ERR_UNSUPPORTED;   // the row must sit in one wave
   const bool two = Q != nullptr;
   switch (w) {
     case 4: return two ? dispatch_reduce<4, true>(a, N, counts, reduce, st)
@@ -726,6 +751,16 @@ int mp_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                     size_t ws_bytes, mp_stream_t stream) {
   return agg_common(rowptr, col, val, N, plan, counts_host, X, ldx, Y, ldy, nullptr, 0, d, reduce, S,
                     lds, self_scale, bias, act, argmax, ws, ws_bytes, as_stream(stream));
+}
+
+int mp_spmm_csr_epilogue_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N,
+                             const int32_t* plan, const int32_t* counts_host, const float* X, int64_t ldx,
+                             float* Y, int64_t ldy, int32_t d, int reduce, const float* S, int64_t lds,
+                             float self_scale, const float* col_scale, const float* col_shift, int act,
+                             int l2_normalize, float l2_eps, void* ws, size_t ws_bytes, mp_stream_t stream) {
+  return agg_common(rowptr, col, val, N, plan, counts_host, X, ldx, Y, ldy, nullptr, 0, d, reduce, S, lds,
+                    self_scale, col_shift, act, nullptr, ws, ws_bytes, as_stream(stream), col_scale,
+                    l2_normalize ? 1 : 0, l2_eps);
 }
 
 int mp_idgnn_agg_f32(const int32_t* rowptr, const int32_t* col_marked, const float* val, int64_t N,

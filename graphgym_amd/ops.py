@@ -95,6 +95,40 @@ def spmm(g, x, reduce="sum", self_scale=0.0, bias=None, relu=False):
     return _SpMM.apply(x, bias, g, _lib.REDUCE[reduce], float(self_scale), bool(relu))
 
 
+def spmm_fused_eval(g, x, reduce="sum", self_scale=0.0, col_scale=None, col_shift=None, relu=False,
+                    l2norm=False, l2_eps=1e-12):
+    """Inference-only aggregation with the layer's post-ops folded into the row flush:
+    act((agg + self_scale * x) * col_scale + col_shift), then optional row L2 normalisation
+    (graphgym/models/layer.py:26-47, gnn.py:79-80 with BatchNorm in eval mode).  No autograd."""
+    x = _f32c(x.detach(), "x")
+    L = lib()
+    N, d = g.num_nodes, x.size(1)
+    y = torch.empty((N, d), dtype=torch.float32, device=x.device)
+    plan, counts = g.plan()
+    red = _lib.REDUCE[reduce]
+    S = x if self_scale != 0.0 else None
+    with torch.cuda.device(x.device):
+        nb = C.c_size_t(0)
+        check(L.mp_spmm_ws_bytes(counts, d, red, 0, C.byref(nb)))
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=x.device) if nb.value else None
+        cs = None if col_scale is None else col_scale.detach().contiguous()
+        ct = None if col_shift is None else col_shift.detach().contiguous()
+        st = L.mp_spmm_csr_epilogue_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val), N, ptr(plan), counts, ptr(x),
+                                        x.stride(0), ptr(y), y.stride(0), d, red, ptr(S),
+                                        S.stride(0) if S is not None else 0, float(self_scale), ptr(cs), ptr(ct),
+                                        _lib.ACT_RELU if relu else _lib.ACT_NONE, 1 if l2norm else 0,
+                                        float(l2_eps), ptr(ws), nb.value, _stream())
+        if st == 2 and l2norm:   # row wider than one wave: normalise in a second pass
+            check(L.mp_spmm_csr_epilogue_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val), N, ptr(plan), counts, ptr(x),
+                                             x.stride(0), ptr(y), y.stride(0), d, red, ptr(S),
+                                             S.stride(0) if S is not None else 0, float(self_scale), ptr(cs),
+                                             ptr(ct), _lib.ACT_RELU if relu else _lib.ACT_NONE, 0, float(l2_eps),
+                                             ptr(ws), nb.value, _stream()), "mp_spmm_csr_epilogue_f32")
+            return torch.nn.functional.normalize(y, p=2, dim=-1, eps=l2_eps)
+        check(st, "mp_spmm_csr_epilogue_f32")
+    return y
+
+
 class _IdAgg(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, id_index, col_marked):

@@ -185,6 +185,21 @@ int mp_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                     void* ws, size_t ws_bytes, mp_stream_t stream);
 
 /*
+ * Inference-time fusion of the layer's post-ops (graphgym/models/layer.py:26-47,
+ * gnn.py:79-80) into the row flush:
+ *   y = act( (reduce + self_scale * S[r]) * col_scale + col_shift ) ; optionally y /= max(||y||_2, l2_eps)
+ * col_scale / col_shift [d] fold conv bias + BatchNorm1d in eval mode (gamma / sqrt(var + eps), ...).
+ * l2_normalize needs the whole row in one wave: d <= 256 (MP_ERR_UNSUPPORTED otherwise).
+ */
+int mp_spmm_csr_epilogue_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                             int64_t N, const int32_t* plan, const int32_t* counts_host,
+                             const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t d,
+                             int reduce, const float* S, int64_t lds, float self_scale,
+                             const float* col_scale, const float* col_shift, int act,
+                             int l2_normalize, float l2_eps,
+                             void* ws, size_t ws_bytes, mp_stream_t stream);
+
+/*
  * ID-GNN two-branch aggregation in one pass over the edges (A7):
  *   P[r,:] = sum_e val[e] * X[col[e],:]
  *   Q[r,:] = sum_{e : source is an identity node} val[e] * X[col[e],:]

@@ -422,3 +422,32 @@ def test_full_size_properties_c2_and_c4(dev):
             close(y[r:r + 1], ref)
         del x, y, G
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("d", [64, 128, 256, 512])
+def test_fused_eval_epilogue(dev, d):
+    """conv bias + BatchNorm1d(eval) + ReLU + row L2-normalise folded into the flush
+    (graphgym/models/layer.py:26-47, gnn.py:79-80) vs the unfused torch ops on the oracle's aggregate"""
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(d)
+    N, E = 900, 12000
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :3000] = 11                                                # a hub row goes through the finalize kernel
+    x = torch.randn(N, d, generator=g)
+    bn = torch.nn.BatchNorm1d(d, eps=1e-5)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(d, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(d, generator=g))
+        bn.running_mean.copy_(torch.randn(d, generator=g))
+        bn.running_var.copy_(torch.rand(d, generator=g) + 0.5)
+    bn.eval()
+    conv_bias = torch.randn(d, generator=g)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N)
+    agg = R.coo_aggregate(ei[1], ei[0], None, x, N, "sum") + 0.5 * x + conv_bias
+    ref = torch.nn.functional.normalize(torch.relu(bn(agg)), p=2, dim=-1).detach()
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias + (conv_bias - bn.running_mean) * scale
+    y = ops.spmm_fused_eval(G, x.to(dev), "sum", self_scale=0.5, col_scale=scale.detach().to(dev),
+                            col_shift=shift.detach().to(dev), relu=True, l2norm=True)
+    close(y, ref)
