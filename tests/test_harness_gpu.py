@@ -94,3 +94,17 @@ def test_idgcn_model_step_matches_oracle(dev):
     for k, p in model.named_parameters():
         g, gr = p.grad.cpu(), P[k].grad
         assert float((g - gr).abs().max()) <= 1e-4 * max(1.0, float(gr.abs().max())), k
+
+
+def test_identity_branch_lifts_accuracy_like_the_reference(dev):
+    """End-to-end band (README.md:104-118): on BA graphs with clustering-coefficient labels the
+    reference reports GCN 0.695 vs ID-GCN Full 0.964.  A short run must reproduce the ordering and
+    a clear gap — the identity branch + ego expansion carry information plain GCN cannot see."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location(
+        "train_synthetic_ba", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "train_synthetic_ba.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gcn = mod.run("gcn", 150, dev)["best_val_acc"]
+    idgcn = mod.run("idgcn", 150, dev)["best_val_acc"]
+    assert idgcn >= gcn + 0.1 and idgcn >= 0.75, (gcn, idgcn)
