@@ -1,0 +1,86 @@
+"""The N > 1 path on the real kernels: two ranks (sharing the box's one GPU, gloo for the exchange —
+RCCL refuses two ranks on one device) each own a shard of the batch's graphs, run the ID-GCN step on
+the engine, all-reduce gradients through GradBucket, and must end with the gradient of the full batch."""
+import os
+import socket
+
+import networkx as nx
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _graphs():
+    return [nx.powerlaw_cluster_graph(24 + 4 * (i % 3), 2, 0.3, seed=i) for i in range(6)]
+
+
+def _union(graphs, dev):
+    parts, off = [], 0
+    for G in graphs:
+        e = np.array(list(G.edges()), dtype=np.int64) + off
+        parts.append(np.concatenate([e, e[:, ::-1]]))
+        off += G.number_of_nodes()
+    return torch.from_numpy(np.concatenate(parts).T.copy()).to(dev), off
+
+
+def _loss_and_grads(graphs, labels, total_centres, dev, bucket_fn=None):
+    import graphgym_amd as ga
+    from graphgym_amd import harness as H
+    from graphgym_amd.ego import ego_batch
+    torch.manual_seed(7)
+    model = H.TfgNodeModel("idgcn", 3, 16, 4).to(dev)
+    ei, n = _union(graphs, dev)
+    base = ga.CSRGraph.from_edge_index(ei, n)
+    ei2, orig, ids, _ = ego_batch(base, torch.arange(n, device=dev), 2)
+    feats = torch.cat([torch.linspace(0, 1, n).view(-1, 1)] * 3, dim=1).to(dev) * torch.tensor([1., -1., .5], device=dev)
+    x = feats[orig]
+    logits = model([x, ei2, ids], holder=H.Batch())
+    y = torch.as_tensor(labels, device=dev)
+    loss = torch.nn.functional.cross_entropy(logits[ids], y, reduction="sum") / total_centres
+    loss.backward()
+    if bucket_fn is not None:
+        bucket_fn(model)
+    return [p.grad.detach().cpu().clone() for p in model.parameters()]
+
+
+def _labels(graphs):
+    return [int(v) % 4 for G in graphs for v in range(G.number_of_nodes())]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MP_SHARE_DEVICE="1", MP_DIST_BACKEND="gloo")
+    from graphgym_amd import dist as D
+    r, _, w = D.init_from_env()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    graphs = _graphs()
+    costs = [2 * G.number_of_edges() for G in graphs]
+    mine = D.lpt_partition(costs, w)[r]
+    total = sum(G.number_of_nodes() for G in graphs)
+    sub = [graphs[i] for i in mine]
+
+    def exchange(model):
+        b = D.GradBucket(model.parameters())
+        b.all_reduce_mean()
+        for p in model.parameters():       # mean over ranks of per-rank sums/total -> x world = full-batch gradient
+            p.grad.mul_(w)
+    grads = _loss_and_grads(sub, _labels(sub), total, dev, exchange)
+    torch.save({"grads": grads, "mine": mine}, os.path.join(out, f"r{rank}.pt"))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_data_parallel_equals_full_batch(dev, tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(tmp_path / "r0.pt", weights_only=True)
+    b = torch.load(tmp_path / "r1.pt", weights_only=True)
+    assert sorted(a["mine"] + b["mine"]) == list(range(6))
+    graphs = _graphs()
+    full = _loss_and_grads(graphs, _labels(graphs), sum(G.number_of_nodes() for G in graphs), dev)
+    for ga_, gb_, gf in zip(a["grads"], b["grads"], full):
+        assert torch.equal(ga_, gb_)
+        assert float((ga_ - gf).abs().max()) <= 1e-5 * max(1.0, float(gf.abs().max()))
