@@ -35,7 +35,9 @@ def _loss_and_grads(graphs, labels, total_centres, dev, bucket_fn=None):
     ei, n = _union(graphs, dev)
     base = ga.CSRGraph.from_edge_index(ei, n)
     ei2, orig, ids, _ = ego_batch(base, torch.arange(n, device=dev), 2)
-    feats = torch.cat([torch.linspace(0, 1, n).view(-1, 1)] * 3, dim=1).to(dev) * torch.tensor([1., -1., .5], device=dev)
+    # per-node features that depend only on the node's own graph (identical in a shard and in the full batch)
+    rows = [[v / G.number_of_nodes(), G.degree(v) / 10.0, nx.clustering(G, v)] for G in graphs for v in range(G.number_of_nodes())]
+    feats = torch.tensor(rows, dtype=torch.float32, device=dev)
     x = feats[orig]
     logits = model([x, ei2, ids], holder=H.Batch())
     y = torch.as_tensor(labels, device=dev)
