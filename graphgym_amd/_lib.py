@@ -54,6 +54,7 @@ PROTOTYPES = {
     "mp_rows_gather_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p]),
     "mp_rows_scatter_add_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p]),
     "mp_sddmm_dot_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _i32, _f32, _p, _p]),
+    "mp_sddmm_dot_stream_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _f32, _p, _p]),
     "mp_sddmm_add_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _f32, _p, _p]),
     "mp_csr_row_softmax_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
     "mp_csr_row_softmax_bwd_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),

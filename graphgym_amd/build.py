@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libmpengine.so")
 SOURCES = ["spmm.hip", "csr_build.hip", "attn.hip", "ego.hip", "util.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "mp_engine.h")]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "vecio.h"), os.path.join(ROOT, "include", "mp_engine.h")]
 ARCH = "gfx950"
 
 

@@ -7,6 +7,7 @@
 // streams the neighbours' keys with coalesced row loads and reduces each head's
 // dot product across its lanes with DPP/permute shuffles.
 #include "common.h"
+#include "vecio.h"
 
 namespace mp {
 
@@ -42,6 +43,81 @@ __global__ __launch_bounds__(kBlock) void sddmm_dot_kernel(const int32_t* __rest
         if (lane == 0) s[(int64_t)e * heads + h] = acc * scale;
       }
     }
+  }
+}
+
+
+// Entry-balanced SDDMM: every wave owns kStream consecutive stored entries (no row ever makes a
+// wave longer than another), reads 64 (row, col) pairs with coalesced loads, broadcasts them to
+// SGPRs and issues two coalesced row loads per entry — A[row] (an L1/L2 hit while the row repeats)
+// and B[col] — U entries in flight.  The per-head dot product is a wave-segment reduction
+// (lanes of one head are contiguous); scores leave the wave as one coalesced store per 64 entries.
+constexpr int kStream = 256;
+
+template <int W, int U>
+__global__ __launch_bounds__(kBlock) void sddmm_stream_kernel(const int32_t* __restrict__ row_of,
+                                                              const int32_t* __restrict__ col, int64_t nnz,
+                                                              const float* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ B, int64_t ldb,
+                                                              int32_t d, int32_t heads, float scale, float* s) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t w0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kStream;
+  if (w0 >= nnz) return;
+  const int64_t w1 = w0 + kStream < nnz ? w0 + kStream : nnz;
+  const int tiles = (d + kWave * W - 1) / (kWave * W);
+  const int gs = (d / heads) / W;        // lanes per head (heads > 1 implies tiles == 1, checked on the host)
+  for (int64_t ec = w0; ec < w1; ec += kWave) {
+    const int64_t me = ec + lane < w1 ? ec + lane : w1 - 1;
+    const int rv = row_of[me];
+    const int cv = col[me];
+    const int n = (int)(w1 - ec < kWave ? w1 - ec : kWave);
+    float res = 0.f;
+    for (int jb = 0; jb < n; jb += U) {
+      float acc[U];
+      int rj[U], cj[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        acc[j] = 0.f;
+        rj[j] = bcast_i(rv, jb + j);
+        cj[j] = bcast_i(cv, jb + j) & 0x7fffffff;
+      }
+      for (int t = 0; t < tiles; ++t) {
+        const int c0 = (t * kWave + lane) * W;
+        const bool on = c0 < d;
+        const int c0ld = on ? c0 : 0;
+        float a[U][W], b[U][W];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          load_vec<W>(A + (int64_t)rj[j] * lda + c0ld, a[j]);
+          load_vec<W>(B + (int64_t)cj[j] * ldb + c0ld, b[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          if (on) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) acc[j] = fmaf(a[j][k], b[j][k], acc[j]);
+          }
+        }
+      }
+      if (heads == 1) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          float t = acc[j];
+          for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
+          if (lane == jb + j) res = t;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          float t = acc[j];
+          for (int off = gs >> 1; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
+          const int64_t e = ec + jb + j;
+          if (e < w1 && (lane % gs) == 0 && lane / gs < heads) s[e * heads + lane / gs] = t * scale;
+        }
+      }
+    }
+    if (heads == 1 && lane < n) s[ec + lane] = res * scale;
   }
 }
 
@@ -151,6 +227,37 @@ int mp_sddmm_dot_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64
   if (N == 0 || nnz == 0) return MP_OK;
   hipLaunchKernelGGL(sddmm_dot_kernel, dim3(row_grid(N)), dim3(kBlock), 0, as_stream(stream), rowptr, col, N,
                      Qm, ldq, Km, ldk, d, heads, scale, s);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+static bool al(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+int mp_sddmm_dot_stream_f32(const int32_t* row_of, const int32_t* col, int64_t nnz, const float* Am,
+                            int64_t lda, const float* Bm, int64_t ldb, int32_t d, int32_t heads, float scale,
+                            float* s, mp_stream_t stream) {
+  if (nnz < 0 || d <= 0 || heads <= 0 || d % heads) return MP_ERR_INVALID_ARG;
+  if (nnz == 0) return MP_OK;
+  if (!row_of || !col || !Am || !Bm || !s || lda < d || ldb < d) return MP_ERR_INVALID_ARG;
+  const int dh = d / heads;
+  int w = 4;
+  auto ok = [&](int ww) {
+    return d % ww == 0 && dh % ww == 0 && lda % ww == 0 && ldb % ww == 0 && al(Am, 4u * ww) && al(Bm, 4u * ww);
+  };
+  while (w > 1 && !ok(w)) w >>= 1;
+  while (w > 1 && kWave * (w / 2) >= d) w >>= 1;
+  if (heads > 1) {
+    const int gs = dh / w;   // lanes per head must be a power of two inside one wave-wide tile
+    if (d > kWave * w || gs < 1 || (gs & (gs - 1)) || kWave % gs) return MP_ERR_UNSUPPORTED;
+  }
+  const int64_t waves = ceil_div(nnz, kStream);
+  dim3 grid((unsigned)ceil_div(waves, kWavesPerBlock));
+  hipStream_t st = as_stream(stream);
+  switch (w) {
+    case 4: hipLaunchKernelGGL((sddmm_stream_kernel<4, 4>), grid, dim3(kBlock), 0, st, row_of, col, nnz, Am, lda, Bm, ldb, d, heads, scale, s); break;
+    case 2: hipLaunchKernelGGL((sddmm_stream_kernel<2, 4>), grid, dim3(kBlock), 0, st, row_of, col, nnz, Am, lda, Bm, ldb, d, heads, scale, s); break;
+    default: hipLaunchKernelGGL((sddmm_stream_kernel<1, 4>), grid, dim3(kBlock), 0, st, row_of, col, nnz, Am, lda, Bm, ldb, d, heads, scale, s); break;
+  }
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

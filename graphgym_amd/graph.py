@@ -100,6 +100,8 @@ class CSRGraph:
         """same sparsity pattern (and plan / transpose pattern), other entry values"""
         g = CSRGraph(self.rowptr, self.col, val, self.eid, self.num_nodes, self.nnz, self.num_cols)
         g._plan = self._plan
+        g._row_ids = getattr(self, "_row_ids", None)
+        g._pattern_of = self if getattr(self, "_pattern_of", None) is None else self._pattern_of
         return g
 
     @property
@@ -152,11 +154,14 @@ class CSRGraph:
         return g
 
     def row_ids(self):
-        L = lib()
-        out = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
-            check(L.mp_csr_row_ids(ptr(self.rowptr), self.num_nodes, self.nnz, ptr(out), _stream()))
-        return out[:self.nnz]
+        """row of every stored entry (cached: the attention kernels stream over it)"""
+        if getattr(self, "_row_ids", None) is None:
+            L = lib()
+            out = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                check(L.mp_csr_row_ids(ptr(self.rowptr), self.num_nodes, self.nnz, ptr(out), _stream()))
+            self._row_ids = out[:self.nnz]
+        return self._row_ids
 
     def entry_counts(self):
         """number of stored entries per row (the divisor of reduce='mean')"""

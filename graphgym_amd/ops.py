@@ -230,13 +230,19 @@ def _raw_sddmm_dot(g, A, B, heads, scale):
     L = lib()
     s = torch.empty(max(g.nnz, 1) * heads, dtype=torch.float32, device=A.device)
     with torch.cuda.device(A.device):
-        check(L.mp_sddmm_dot_f32(ptr(g.rowptr), ptr(g.col), g.num_nodes, g.nnz, ptr(A), A.stride(0),
-                                 ptr(B), B.stride(0), A.size(1), heads, float(scale), ptr(s), _stream()),
-              "mp_sddmm_dot_f32")
+        st = L.mp_sddmm_dot_stream_f32(ptr(g.row_ids()), ptr(g.col), g.nnz, ptr(A), A.stride(0), ptr(B),
+                                       B.stride(0), A.size(1), heads, float(scale), ptr(s), _stream())
+        if st == 2:   # head layout the entry-balanced kernel does not cover
+            st = L.mp_sddmm_dot_f32(ptr(g.rowptr), ptr(g.col), g.num_nodes, g.nnz, ptr(A), A.stride(0),
+                                    ptr(B), B.stride(0), A.size(1), heads, float(scale), ptr(s), _stream())
+        check(st, "mp_sddmm_dot")
     return s[:g.nnz * heads].view(g.nnz, heads)
 
 
 def _raw_spmm_heads(g, a, V, heads):
+    if heads == 1:   # one weight per entry: this is the hot aggregation kernel with val = a
+        y, _ = _raw_spmm(g.with_values(a.reshape(-1).contiguous()), V, _lib.SUM)
+        return y
     L = lib()
     y = torch.empty((g.num_nodes, V.size(1)), dtype=torch.float32, device=V.device)
     with torch.cuda.device(V.device):

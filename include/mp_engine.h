@@ -239,6 +239,12 @@ int mp_sddmm_dot_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64
                      const float* Qm, int64_t ldq, const float* Km, int64_t ldk,
                      int32_t d, int32_t heads, float scale, float* s,
                      mp_stream_t stream);
+/* the same scores on the entry-balanced kernel: needs row_of (mp_csr_row_ids) instead of rowptr;
+ * heads > 1 needs d <= 256 and (d / heads / vector width) a power of two (MP_ERR_UNSUPPORTED
+ * otherwise: use mp_sddmm_dot_f32) */
+int mp_sddmm_dot_stream_f32(const int32_t* row_of, const int32_t* col, int64_t nnz,
+                            const float* A, int64_t lda, const float* B, int64_t ldb,
+                            int32_t d, int32_t heads, float scale, float* s, mp_stream_t stream);
 /* additive scores: s[e] = leaky_relu(ai[row] + aj[col], slope) (idconv.py:319-326
  * with ai = <z, att[:d]>, aj = <z, att[d:]> precomputed per node) */
 int mp_sddmm_add_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t nnz,

@@ -31,6 +31,6 @@ def run(kind, n, d, f_in, iters=5):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    for kind in ("gcn", "idgcn", "sage", "idsage", "gin", "idgin"):
+    for kind in ("gcn", "idgcn", "sage", "idsage", "gin", "idgin", "gat", "idgat"):
         run(kind, n, 256, 256)
     run("gcn", n, 256, 1)
