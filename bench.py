@@ -35,14 +35,14 @@ def algorithmic_bytes(n, nnz, d, weighted):
     return nnz * d * 4 + n * d * 4 + nnz * 4 + (nnz * 4 if weighted else 0) + (n + 1) * 4
 
 
-def cpu_baseline(g, x, seconds=12.0):
+def cpu_baseline(g, x, seconds=15.0):
     """oracle/ref_ops.coo_aggregate_sum_chunked on the leading edge chunks of the same graph"""
     from oracle import ref_ops
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     n, d = x.shape
     chunk = 4_000_000
-    take = min(g.nnz, 6 * chunk)
+    take = min(g.nnz, 25 * chunk)
     dst = g.row_ids()[:take].long().cpu()
     src = g.col[:take].long().cpu()
     w = g.val[:take].cpu() if g.val is not None else None

@@ -154,6 +154,9 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
   constexpr bool NT_ST = VAR & 1;
   constexpr bool NT_IDX = VAR & 2;
   constexpr bool PREF = VAR & 4;
+  constexpr bool LDS_TILE = VAR & 8;   // the index / value tile staged through LDS instead of v_readlane
+  __shared__ int lds_col[LDS_TILE ? kWavesPerBlock * kWave : 1];
+  __shared__ float lds_val[LDS_TILE ? kWavesPerBlock * kWave : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int seg = blockIdx.x * kWavesPerBlock + wave;
@@ -217,12 +220,18 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
       load_idx(ec, cv, wv);
     }
     const int n = min(kWave, e1 - ec);
+    if constexpr (LDS_TILE) {
+      lds_col[wave * kWave + lane] = cv;
+      if (WEIGHTED) lds_val[wave * kWave + lane] = wv;
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is wave-private, no barrier needed
+    }
     for (int jb = 0; jb < n; jb += U) {
       float v[U][W];
       int cj[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        cj[j] = bcast_i(cv, jb + j);
+        if constexpr (LDS_TILE) cj[j] = __builtin_amdgcn_readfirstlane(lds_col[wave * kWave + jb + j]);
+        else cj[j] = bcast_i(cv, jb + j);
         const int c = BRANCH2 ? (cj[j] & 0x7fffffff) : cj[j];
         load_vec<W>(xlane + (int64_t)c * a.ldx, v[j]);
       }
@@ -234,7 +243,14 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
             finish_row<W, REDUCE, BRANCH2, NT_ST>(a, r, rend - rstart, acc, c0, c0ld, lane_on);
             advance();
           }
-          const float w = WEIGHTED ? bcast_f(wv, jb + j) : 1.f;
+          float w = 1.f;
+          if (WEIGHTED) {
+            if constexpr (LDS_TILE)
+              w = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+                      __builtin_bit_cast(int, lds_val[wave * kWave + jb + j])));
+            else
+              w = bcast_f(wv, jb + j);
+          }
           acc.add(v[j], w, BRANCH2 && cj[j] < 0, e);
         }
       }
@@ -459,6 +475,7 @@ static int launch_agg(const AggArgs& a, int64_t N, const int32_t* counts, hipStr
     }
     MP_VARIANT(4, 0) MP_VARIANT(16, 0) MP_VARIANT(8, 0) MP_VARIANT(8, 2) MP_VARIANT(8, 3)
     MP_VARIANT(8, 4) MP_VARIANT(8, 5) MP_VARIANT(8, 7) MP_VARIANT(16, 7) MP_VARIANT(16, 1) MP_VARIANT(4, 7)
+    MP_VARIANT(8, 9)
 #undef MP_VARIANT
   }
   if (!launched)
@@ -616,7 +633,7 @@ int mp_spmm_plan_config(int seg_cost, int row_cost, int hub_deg, int piece_edges
 
 int mp_spmm_kernel_config(int rows_in_flight, int variant_bits) {
   if (rows_in_flight != 4 && rows_in_flight != 8 && rows_in_flight != 16) return MP_ERR_INVALID_ARG;
-  if (variant_bits < 0 || variant_bits > 7) return MP_ERR_INVALID_ARG;
+  if (variant_bits < 0 || variant_bits > 15) return MP_ERR_INVALID_ARG;
   g_unroll = rows_in_flight;
   g_var = variant_bits;
   return MP_OK;

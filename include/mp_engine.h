@@ -148,7 +148,8 @@ int mp_mark_id_sources(const int32_t* col, int64_t nnz, const int64_t* id_index,
 int mp_spmm_plan_config(int seg_cost, int row_cost, int hub_deg, int piece_edges);
 /* tuning knobs of the hot kernel's headline instantiation (fp32 x4, weighted sum); other
  * instantiations ignore them.  rows_in_flight in {4, 8, 16}; variant_bits: 1 = non-temporal
- * stores of Y, 2 = non-temporal index loads, 4 = prefetch of the next index tile.  Default 8, 1. */
+ * stores of Y, 2 = non-temporal index loads, 4 = prefetch of the next index tile, 8 = index tile
+ * staged through LDS instead of v_readlane (kept for the record: DESIGN.md §7).  Default 8, 1. */
 int mp_spmm_kernel_config(int rows_in_flight, int variant_bits);
 int mp_spmm_plan_bytes(int64_t N, int64_t nnz, size_t* bytes_host);
 /* counts_host[8] <- {n_seg, n_hub, n_piece, cap_hub, cap_piece, seg_cost, hub_deg,

@@ -105,6 +105,6 @@ def test_identity_branch_lifts_accuracy_like_the_reference(dev):
         "train_synthetic_ba", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "train_synthetic_ba.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    gcn = mod.run("gcn", 150, dev)["best_val_acc"]
-    idgcn = mod.run("idgcn", 150, dev)["best_val_acc"]
-    assert idgcn >= gcn + 0.1 and idgcn >= 0.75, (gcn, idgcn)
+    gcn = mod.run("gcn", 300, dev)["best_val_acc"]
+    idgcn = mod.run("idgcn", 300, dev)["best_val_acc"]
+    assert idgcn >= gcn + 0.1 and idgcn >= 0.85, (gcn, idgcn)
