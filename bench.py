@@ -2,7 +2,7 @@
 """Headline benchmark of the hot path (BASELINE.json: "aggregated edges/sec + achieved HBM GB/s,
 GCN d=256 on 100M-edge scale-free").
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -74,8 +74,8 @@ def pmc_traffic(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--m", type=int, default=5)
     ap.add_argument("--d", type=int, default=256)
@@ -121,7 +121,8 @@ def main():
     dt = time.perf_counter() - t0
     dt = D.all_reduce_max(dt, dev)
     total_nnz = D.all_reduce_sum(g.nnz, dev)
-    launch_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / args.steps
+    per_step = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
+    launch_ms = sum(per_step) / args.steps
 
     if rank == 0:
         balg = algorithmic_bytes(n, g.nnz, d, g.val is not None)
@@ -143,6 +144,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(workload),
                          "algorithmic_bytes_per_launch": balg, "launch_ms": launch_ms,
+                         "launch_ms_min_median_max": [per_step[0], per_step[len(per_step) // 2], per_step[-1]],
                          "kernel": "mp::agg_rows_kernel<4,SUM,weighted> (+ hub pieces/finalize, same launch group)"},
         }
         if world == 1 and not args.no_cpu_baseline:
