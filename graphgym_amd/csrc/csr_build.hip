@@ -177,26 +177,32 @@ __global__ __launch_bounds__(kBlock) void transpose_emit_kernel(const uint64_t* 
   }
 }
 
+// Rows are walked by groups of kRowLanes lanes (4 rows per wave): short rows keep most lanes busy and a
+// 10^4-entry hub row is split over the group instead of serialising one thread.
+constexpr int kRowLanes = 16;
+
 __global__ __launch_bounds__(kBlock) void degree_row_kernel(const int32_t* __restrict__ rowptr,
                                                             const float* __restrict__ val, int64_t N,
                                                             float* deg) {
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N;
-       r += (int64_t)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x % kRowLanes;
+  const int64_t groups = (int64_t)gridDim.x * (kBlock / kRowLanes);
+  for (int64_t r = (int64_t)blockIdx.x * (kBlock / kRowLanes) + threadIdx.x / kRowLanes; r < N; r += groups) {
     const int s = rowptr[r], e = rowptr[r + 1];
     float acc = 0.f;
     if (val) {
-      // compensated (Kahan) sum: hub rows add 10^4 terms, a plain fp32 running sum drifts ~1e-4 relative
+      // per-lane compensated (Kahan) partial sums, then a 16-lane tree: hub rows add 10^4 terms
       float comp = 0.f;
-      for (int k = s; k < e; ++k) {
+      for (int k = s + sub; k < e; k += kRowLanes) {
         const float yv = val[k] - comp;
         const float t = acc + yv;
         comp = (t - acc) - yv;
         acc = t;
       }
+      for (int off = kRowLanes >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kRowLanes);
     } else {
       acc = (float)(e - s);
     }
-    deg[r] = acc;
+    if (sub == 0) deg[r] = acc;
   }
 }
 
@@ -224,11 +230,12 @@ __global__ __launch_bounds__(kBlock) void norm_edges_kernel(const int32_t* __res
                                                             const float* __restrict__ val,
                                                             const float* __restrict__ dinv, int64_t N,
                                                             float* val_out) {
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N;
-       r += (int64_t)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x % kRowLanes;
+  const int64_t groups = (int64_t)gridDim.x * (kBlock / kRowLanes);
+  for (int64_t r = (int64_t)blockIdx.x * (kBlock / kRowLanes) + threadIdx.x / kRowLanes; r < N; r += groups) {
     const int s = rowptr[r], e = rowptr[r + 1];
     const float dr = dinv[r];
-    for (int k = s; k < e; ++k) {
+    for (int k = s + sub; k < e; k += kRowLanes) {
       const float w = val ? val[k] : 1.f;
       val_out[k] = dr * w * dinv[col[k]];  // (D^-1/2 A) D^-1/2: TfgIDLayer.py:558, idconv.py:60,148
     }
@@ -405,7 +412,7 @@ int mp_csr_degree(const int32_t* rowptr, const int32_t* col, const float* val, i
   if (N == 0) return MP_OK;
   hipStream_t st = as_stream(stream);
   if (axis == MP_AXIS_ROW) {
-    hipLaunchKernelGGL(degree_row_kernel, dim3(flat_grid(N)), dim3(kBlock), 0, st, rowptr, val, N, deg);
+    hipLaunchKernelGGL(degree_row_kernel, dim3(flat_grid(N * kRowLanes)), dim3(kBlock), 0, st, rowptr, val, N, deg);
     MP_LAUNCH_CHECK();
   } else if (axis == MP_AXIS_COL) {
     if (nnz > 0 && !col) return MP_ERR_INVALID_ARG;
@@ -430,7 +437,7 @@ int mp_gcn_norm_edges(const int32_t* rowptr, const int32_t* col, const float* va
   hipLaunchKernelGGL(inv_sqrt_kernel, dim3(flat_grid(N)), dim3(kBlock), 0, st, dinv_out, N);
   MP_LAUNCH_CHECK();
   if (nnz > 0) {
-    hipLaunchKernelGGL(norm_edges_kernel, dim3(flat_grid(N)), dim3(kBlock), 0, st, rowptr, col, val,
+    hipLaunchKernelGGL(norm_edges_kernel, dim3(flat_grid(N * kRowLanes)), dim3(kBlock), 0, st, rowptr, col, val,
                        dinv_out, N, val_out);
     MP_LAUNCH_CHECK();
   }
