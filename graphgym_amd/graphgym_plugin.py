@@ -15,7 +15,7 @@ registered keys (layer.py:238), so taking over an existing key is done by assign
 dictionaries — ``install(override=True)``, the default.
 """
 from . import layers as L
-from . import register as R
+from . import registry as R
 
 ID_KEYS = {
     'idconv': L.GeneralIDConv,

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from . import layers as L
 from .config import cfg
-from .register import layer_dict
+from .registry import layer_dict
 
 
 class Batch(types.SimpleNamespace):

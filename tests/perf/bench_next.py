@@ -5,10 +5,12 @@
      and a batch of centres on a 10^6-node graph
   3. one ID-GCN training step on an ego batch (config C3 shape, d = 128)
 
-    python scripts/bench_next.py > profiles/r01_next.jsonl
+    python tests/perf/bench_next.py > profiles/r01_next.jsonl
+
+Lives under tests/ because it times the CPU oracle next to the engine (oracle/ is test infrastructure).
 """
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import networkx as nx
 import numpy as np
 import torch

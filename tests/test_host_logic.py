@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 
 
 def test_registry_semantics_match_reference():
-    from graphgym_amd import register as R
+    from graphgym_amd import registry as R
     d = {}
     R.register("a", int, d)
     with pytest.raises(KeyError, match="already pre-defined"):

@@ -270,7 +270,7 @@ def test_tf_gat(dev, rec):
 # ---- the GraphGym boundary: layer_dict[key](dim_in, dim_out, bias=...)(batch) ---------------
 def test_registered_keys_run_on_a_batch(dev, rec):
     import graphgym_amd.graphgym_plugin as plugin
-    from graphgym_amd.register import layer_dict
+    from graphgym_amd.registry import layer_dict
     ei = torch.from_numpy(rec["edge_index"]).to(dev)
     ids = torch.from_numpy(rec["node_id_index"]).to(dev)
     for key in plugin.ALL_KEYS:
