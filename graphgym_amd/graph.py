@@ -111,6 +111,10 @@ class CSRGraph:
     # ---- plan --------------------------------------------------------------
     def plan(self):
         if self._plan is None:
+            src = getattr(self, "_pattern_of", None)
+            if src is not None and src is not self:
+                self._plan = src.plan()       # same rowptr, same segmentation
+                return self._plan
             L = lib()
             with torch.cuda.device(self.device):
                 nb = C.c_size_t(0)
@@ -124,8 +128,19 @@ class CSRGraph:
 
     # ---- derived graphs ----------------------------------------------------
     def transpose(self):
-        """CSR of A^T (rows = sources) with values permuted; cached."""
+        """CSR of A^T (rows = sources) with values permuted; cached.  Graphs that share a sparsity
+        pattern (with_values / gcn_norm) share one sorted transpose pattern and only permute values."""
         if self._t is None:
+            src = getattr(self, "_pattern_of", None)
+            if src is not None and src is not self:
+                t0 = src.transpose()
+                t = CSRGraph(t0.rowptr, t0.col, None if self.val is None else self.val[t0.pos.long()], None,
+                             t0.num_nodes, t0.nnz, t0.num_cols)
+                t._plan = t0._plan if t0._plan is not None else None
+                t.pos = t0.pos
+                t._pattern_of = t0
+                self._t = t
+                return t
             L = lib()
             R, N, nnz, dev = self.num_nodes, self.num_cols, self.nnz, self.device
             with torch.cuda.device(dev):
@@ -200,7 +215,6 @@ class CSRGraph:
                                       ptr(val_out), ptr(dinv), _stream()), "mp_gcn_norm_edges")
         g = self.with_values(val_out[:nnz])
         g.dinv = dinv[:N]
-        g._t = None
         return g
 
     def mark_ids(self, id_index):
