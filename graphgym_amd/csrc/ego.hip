@@ -68,32 +68,51 @@ __global__ __launch_bounds__(kBlock) void ego_seed_kernel(const int64_t* __restr
   }
 }
 
-// one BFS level: grid (chunks, B); every set bit of `frontier` pushes its neighbours
+// Wave-wide walk over the set bits of a bitmap: a wave loads 64 words at once, skips empty ones with a
+// ballot, and hands every member node v to `body(v)` with v wave-uniform — so the 64 lanes can split
+// v's neighbour list (coalesced col reads; a 10^4-neighbour hub no longer serialises one thread).
+template <class Body>
+__device__ __forceinline__ void for_each_member(const uint32_t* __restrict__ bitmap, int64_t W, Body body) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * kWave;
+  for (int64_t wbase = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kWave; wbase < W; wbase += stride) {
+    const int64_t w = wbase + lane;
+    const uint32_t mine = w < W ? bitmap[w] : 0u;
+    unsigned long long nz = __ballot(mine != 0u);
+    while (nz) {
+      const int src = __builtin_ctzll(nz);
+      nz &= nz - 1;
+      uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)mine, src);
+      while (bits) {
+        const int b = __builtin_ctz(bits);
+        bits &= bits - 1;
+        body((uint32_t)((wbase + src) * 32 + b));
+      }
+    }
+  }
+}
+
+// one BFS level: grid (chunks, B); every member of `frontier` pushes its neighbours
 __global__ __launch_bounds__(kBlock) void ego_level_kernel(const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col, int64_t W,
                                                            const uint32_t* __restrict__ frontier,
                                                            uint32_t* visited, uint32_t* next) {
   const int64_t c = blockIdx.y;
-  const uint32_t* fr = frontier + c * W;
+  const int lane = threadIdx.x & 63;
   uint32_t* vis = visited + c * W;
   uint32_t* nx = next + c * W;
-  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < W; w += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t bits = fr[w];
-    while (bits) {
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1;
-      const int64_t v = w * 32 + b;
-      const int s = rowptr[v], e = rowptr[v + 1];
-      for (int k = s; k < e; ++k) {
-        const uint32_t u = (uint32_t)col[k] & 0x7fffffffu;
-        const uint32_t m = 1u << (u & 31);
-        if (!(vis[u >> 5] & m)) {
-          const uint32_t old = atomicOr(&vis[u >> 5], m);
-          if (!(old & m)) atomicOr(&nx[u >> 5], m);
-        }
+  for_each_member(frontier + c * W, W, [&](uint32_t v) {
+    const int s = rowptr[v], e = rowptr[v + 1];
+    for (int k = s + lane; k < e; k += kWave) {
+      const uint32_t u = (uint32_t)col[k] & 0x7fffffffu;
+      const uint32_t m = 1u << (u & 31);
+      if (!(vis[u >> 5] & m)) {
+        const uint32_t old = atomicOr(&vis[u >> 5], m);
+        if (!(old & m)) atomicOr(&nx[u >> 5], m);
       }
     }
-  }
+  });
 }
 
 // per centre: exclusive prefix of popcounts over the bitmap words; one workgroup per centre
@@ -157,40 +176,41 @@ __global__ __launch_bounds__(kBlock) void ego_edges_kernel(const int32_t* __rest
                                                            int64_t* out_src, int64_t* out_dst, int64_t* orig,
                                                            int32_t* ego_of) {
   const int64_t c = blockIdx.y;
+  const int lane = threadIdx.x & 63;
   const uint32_t* vis = visited + c * W;
   const int32_t* wp = wprefix + c * W;
   const int64_t centre = centres[c];
   const int64_t noff = PASS ? node_off[c] : 0;
+  const int64_t eoff = PASS ? edge_off[c] : 0;
   long long local = 0;
-  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < W; w += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t bits = vis[w];
-    while (bits) {
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1;
-      const uint32_t v = (uint32_t)(w * 32 + b);
-      const int s = rowptr[v], e = rowptr[v + 1];
-      int64_t vid = 0;
-      if (PASS) {
-        vid = ego_new_id(vis, wp, noff, centre, c, v);
+  for_each_member(vis, W, [&](uint32_t v) {
+    const int s = rowptr[v], e = rowptr[v + 1];
+    int64_t vid = 0;
+    if (PASS) {
+      vid = ego_new_id(vis, wp, noff, centre, c, v);
+      if (lane == 0) {
         orig[vid] = (int64_t)v;
         if (ego_of) ego_of[vid] = (int32_t)c;
       }
-      for (int k = s; k < e; ++k) {
-        const uint32_t u = (uint32_t)col[k] & 0x7fffffffu;
-        if (vis[u >> 5] & (1u << (u & 31))) {
-          if (PASS) {
-            const unsigned long long slot = atomicAdd(&cursor[c], 1ull);
-            const int64_t o = edge_off[c] + (int64_t)slot;
-            out_dst[o] = vid;                                         // row v holds v's in-edges
-            out_src[o] = ego_new_id(vis, wp, noff, centre, c, u);
-          } else {
-            ++local;
-          }
+    }
+    for (int k = s + lane; k < e; k += kWave) {
+      const uint32_t u = (uint32_t)col[k] & 0x7fffffffu;
+      if (vis[u >> 5] & (1u << (u & 31))) {
+        if (PASS) {
+          const unsigned long long slot = atomicAdd(&cursor[c], 1ull);   // one add per wave after hipcc's coalescing
+          const int64_t o = eoff + (int64_t)slot;
+          out_dst[o] = vid;                                              // row v holds v's in-edges
+          out_src[o] = ego_new_id(vis, wp, noff, centre, c, u);
+        } else {
+          ++local;
         }
       }
     }
+  });
+  if (!PASS) {
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, kWave);
+    if (lane == 0 && local) atomicAdd((unsigned long long*)&edge_cnt[c], (unsigned long long)local);
   }
-  if (!PASS && local) atomicAdd((unsigned long long*)&edge_cnt[c], (unsigned long long)local);
 }
 
 __global__ void ego_edge_off_kernel(const int64_t* __restrict__ edge_cnt, int64_t B, int64_t* edge_off) {
@@ -202,7 +222,7 @@ __global__ void ego_edge_off_kernel(const int64_t* __restrict__ edge_cnt, int64_
 }
 
 static dim3 ego_grid(int64_t W, int64_t B) {
-  int64_t bx = ceil_div(W, kBlock);
+  int64_t bx = ceil_div(W, kBlock);   // one wave per 64 words, four waves per block
   if (bx < 1) bx = 1;
   if (bx > 512) bx = 512;
   return dim3((unsigned)bx, (unsigned)B);

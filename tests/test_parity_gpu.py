@@ -451,3 +451,38 @@ def test_fused_eval_epilogue(dev, d):
     y = ops.spmm_fused_eval(G, x.to(dev), "sum", self_scale=0.5, col_scale=scale.detach().to(dev),
                             col_shift=shift.detach().to(dev), relu=True, l2norm=True)
     close(y, ref)
+
+
+def test_randomised_graphs_under_a_tiny_plan(dev):
+    """Stress the segmentation and the hub split: with seg_cost / hub_deg / piece_edges forced down to 64
+    every moderately long row becomes a hub cut into pieces and every segment holds a handful of rows.
+    60 random graphs x 3 reduces x weighted/unweighted against the oracle."""
+    import graphgym_amd as ga
+    from graphgym_amd import ops, _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(2024)
+    assert L.mp_spmm_plan_config(64, 1, 64, 64) == 0
+    try:
+        for trial in range(60):
+            N = int(torch.randint(1, 400, (1,), generator=g))
+            E = int(torch.randint(0, 6000, (1,), generator=g))
+            d = [1, 3, 4, 8, 33, 64, 100, 128, 256, 320][trial % 10]
+            ei = torch.randint(0, N, (2, E), generator=g)
+            if E and trial % 3 == 0:                                  # concentrate destinations: long rows
+                ei[1] = ei[1] % max(1, N // 20)
+            if E and trial % 7 == 0:                                  # long runs of empty rows
+                ei[1] = (ei[1] // 50) * 50
+            w = torch.rand(E, generator=g) - 0.3
+            x = torch.randn(N, d, generator=g)
+            for ww in (None, w):
+                G = ga.CSRGraph.from_edge_index(ei.to(dev), N, None if ww is None else ww.to(dev))
+                for red in ("sum", "mean", "max"):
+                    close(ops.spmm(G, x.to(dev), red), R.coo_aggregate(ei[1], ei[0], ww, x, N, red))
+            ids = torch.randperm(N, generator=g)[:max(1, N // 10)]
+            G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev))
+            P, Q = ops.idgnn_aggregate(G, ids.to(dev), x.to(dev))
+            sel = torch.zeros(N, 1); sel[ids] = 1
+            close(P, R.coo_aggregate(ei[1], ei[0], w, x, N, "sum"))
+            close(Q, R.coo_aggregate(ei[1], ei[0], w, x * sel, N, "sum"))
+    finally:
+        assert L.mp_spmm_plan_config(320, 4, 1024, 256) == 0
