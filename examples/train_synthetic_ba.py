@@ -47,7 +47,7 @@ def union(graphs, labels, dev):
     return ei, y, off
 
 
-def run(kind, epochs, dev, seed=0, radius=3, d=128):
+def run(kind, epochs, dev, seed=0, radius=3, d=128, hipgraph=False):
     graphs, labels, n_cls = make_dataset(seed=0)
     torch.manual_seed(seed)
     split = int(0.8 * len(graphs))
@@ -63,31 +63,41 @@ def run(kind, epochs, dev, seed=0, radius=3, d=128):
             sets[name] = dict(ei=ei, x=torch.ones(n, 1, device=dev), ids=None, y=y,
                               label_index=torch.arange(n, device=dev), holder=H.Batch())
     model = H.TfgNodeModel(kind, 1, d, n_cls).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=hipgraph)
 
     def logits(s):
         inputs = [s["x"], s["ei"]] + ([s["ids"]] if s["ids"] is not None else [])
         return model(inputs, holder=s["holder"])
 
-    best, t0 = 0.0, time.time()
+    best = 0.0
+    tr = sets["train"]
+    train_loss = lambda: H.tfg_loss(logits(tr), tr["label_index"], tr["y"], model.kernel_parameters())
+    model.train()
+    graphed = H.GraphedTrainStep(model, opt, train_loss) if hipgraph else None   # full-batch: same shapes every epoch
+    torch.cuda.synchronize()
+    t0 = time.time()
     for ep in range(epochs):
         model.train()
-        s = sets["train"]
-        H.train_step(model, opt, lambda: H.tfg_loss(logits(s), s["label_index"], s["y"], model.kernel_parameters()))
+        if graphed is not None:
+            graphed()
+        else:
+            H.train_step(model, opt, train_loss)
         if ep % 10 == 0 or ep == epochs - 1:
             model.eval()
             with torch.no_grad():
                 v = sets["val"]
                 acc = float((logits(v)[v["label_index"]].argmax(1) == v["y"]).float().mean())
             best = max(best, acc)
-    return {"model": kind, "epochs": epochs, "best_val_acc": best, "seconds": time.time() - t0,
+    torch.cuda.synchronize()
+    return {"model": kind, "epochs": epochs, "hipgraph": hipgraph, "best_val_acc": best, "seconds": time.time() - t0,
             "classes": n_cls, "train_nodes": int(sets["train"]["x"].size(0))}
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=300)
+    ap.add_argument("--hipgraph", action="store_true", help="capture the training step into a HIP graph")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for kind in ("gcn", "idgcn", "gin", "idgin"):
-        print(json.dumps(run(kind, args.epochs, dev)), flush=True)
+        print(json.dumps(run(kind, args.epochs, dev, hipgraph=args.hipgraph)), flush=True)

@@ -177,3 +177,33 @@ def train_step(model, optimizer, forward_loss, bucket=None):
         bucket.all_reduce_mean()
     optimizer.step()
     return loss.detach()
+
+
+class GraphedTrainStep:
+    """The whole step (forward, loss, backward, optimizer) captured once into a HIP graph and replayed.
+
+    The reference trains full-batch on small graphs (batch_size >= dataset in config/*_tf/*.yaml), where a
+    step is ~100 short kernels and launch overhead dominates; shapes repeat every epoch, so one capture
+    serves the run.  Requirements: the batch's CSR / plan / transpose are already cached (run a few eager
+    steps first — done here), the optimizer is capture-safe (torch.optim.Adam(capturable=True)), and
+    forward_loss() reads only tensors that stay at fixed addresses.  Engine ops are capture-safe: they
+    enqueue on torch's current stream and never synchronise once the graph structures are cached."""
+
+    def __init__(self, model, optimizer, forward_loss, warmup=3):
+        self.optimizer = optimizer
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                train_step(model, optimizer, forward_loss)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = forward_loss()
+            self.loss.backward()
+            optimizer.step()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.loss

@@ -108,3 +108,27 @@ def test_identity_branch_lifts_accuracy_like_the_reference(dev):
     gcn = mod.run("gcn", 300, dev)["best_val_acc"]
     idgcn = mod.run("idgcn", 300, dev)["best_val_acc"]
     assert idgcn >= gcn + 0.1 and idgcn >= 0.85, (gcn, idgcn)
+
+
+def test_hip_graph_replay_matches_eager_training(dev):
+    """the captured step (forward + backward + Adam in one HIP graph) follows the eager trajectory"""
+    from graphgym_amd import harness as H
+    batch, _ = make_batch(dev, seed=9)
+    x0 = batch.node_feature
+    losses = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(4)
+        model = H.TfgNodeModel("idgcn", 6, 32, 4).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+        holder = H.Batch()
+
+        def fl():
+            logits = model([x0, batch.edge_index, batch.node_id_index], holder=holder)
+            return H.tfg_loss(logits, batch.node_label_index, batch.node_label, model.kernel_parameters())
+        if mode == "eager":
+            losses[mode] = [float(H.train_step(model, opt, fl)) for _ in range(13)]
+        else:
+            step = H.GraphedTrainStep(model, opt, fl, warmup=3)          # 3 eager steps, then replays
+            losses[mode] = [None] * 3 + [float(step()) for _ in range(10)]
+    for a, b in zip(losses["eager"][3:], losses["graph"][3:]):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (losses["eager"], losses["graph"])
