@@ -99,5 +99,5 @@ if __name__ == "__main__":
     ap.add_argument("--hipgraph", action="store_true", help="capture the training step into a HIP graph")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    for kind in ("gcn", "idgcn", "gin", "idgin"):
+    for kind in ("gcn", "idgcn", "sage", "idsage", "gat", "idgat", "gin", "idgin"):
         print(json.dumps(run(kind, args.epochs, dev, hipgraph=args.hipgraph)), flush=True)
