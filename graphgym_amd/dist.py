@@ -111,3 +111,82 @@ class GradBucket:
                 p.grad = v.clone()
             else:
                 p.grad.copy_(v)
+
+
+# ---- one graph partitioned by destination rows ("one giant graph") ----------------
+class RowPartition:
+    """Contiguous, nnz-balanced destination-row ranges of one CSRGraph, one per rank.
+
+    Rank p owns rows R_p of the adjacency and of every hidden matrix H.  An aggregation needs source
+    rows it does not own (on a scale-free graph: nearly all of them), so each layer exchanges
+    features: all-gather of H before the local aggregation, reduce-scatter of dH in backward.  At the
+    headline size that is 8.96 GB received per GPU per layer over xGMI (>= 8.4 ms at 7 x 153 GB/s)
+    against 2.6 ms of local aggregation — the step is xGMI-bound, which is why the independent-unit
+    sharding above is the scaling mode of record."""
+
+    def __init__(self, graph, rank=None, world=None):
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        n = graph.num_nodes
+        targets = torch.arange(1, self.world, device=graph.device, dtype=torch.int64) * graph.nnz // self.world
+        cuts = torch.searchsorted(graph.rowptr.to(torch.int64), targets).clamp(max=n).tolist()
+        self.bounds = [0] + cuts + [n]
+        for i in range(1, len(self.bounds)):            # keep the ranges monotone
+            self.bounds[i] = max(self.bounds[i], self.bounds[i - 1])
+        self.num_nodes = n
+        self.local = graph.row_slice(self.bounds[self.rank], self.bounds[self.rank + 1])
+        self.max_rows = max(self.bounds[i + 1] - self.bounds[i] for i in range(self.world))
+
+    @property
+    def rows(self):
+        return self.bounds[self.rank], self.bounds[self.rank + 1]
+
+
+def _gather_rows(part, h_loc):
+    """[rows_p, d] on every rank -> [N, d] everywhere (all-gather with padding to the widest range)"""
+    if part.world == 1:
+        return h_loc
+    d = h_loc.size(1)
+    pad = torch.zeros((part.max_rows, d), dtype=h_loc.dtype, device=h_loc.device)
+    pad[:h_loc.size(0)] = h_loc
+    host = dist.get_backend() == "gloo" and pad.is_cuda
+    buf = [torch.empty_like(pad.cpu() if host else pad) for _ in range(part.world)]
+    dist.all_gather(buf, pad.cpu() if host else pad)
+    out = torch.cat([buf[p][:part.bounds[p + 1] - part.bounds[p]] for p in range(part.world)], dim=0)
+    return out.to(h_loc.device)
+
+
+def _scatter_sum_rows(part, full):
+    """sum of [N, d] partials over ranks, each rank keeping its own rows (reduce-scatter)"""
+    if part.world == 1:
+        return full
+    host = dist.get_backend() == "gloo" and full.is_cuda
+    t = full.cpu() if host else full.contiguous()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)     # RCCL: reduce_scatter_tensor would move 1/world of this
+    r0, r1 = part.rows
+    return t[r0:r1].to(full.device)
+
+
+class _HaloAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h_loc, part, reduce):
+        from . import _lib as L_, ops
+        h_full = _gather_rows(part, h_loc.contiguous())
+        z_loc, _ = ops._raw_spmm(part.local, h_full, L_.REDUCE[reduce])
+        ctx.part, ctx.reduce = part, reduce
+        return z_loc
+
+    @staticmethod
+    def backward(ctx, dz_loc):
+        from . import _lib as L_, ops
+        part = ctx.part
+        gt = part.local.transpose() if ctx.reduce != "mean" else part.local.transpose_mean()
+        partial, _ = ops._raw_spmm(gt, dz_loc.contiguous(), L_.SUM)       # [N, d]: this rank's rows' contribution
+        return _scatter_sum_rows(part, partial), None, None
+
+
+def halo_aggregate(part, h_loc, reduce="sum"):
+    """z[R_p] = reduce_j A[R_p, j] h[j] with h row-partitioned like the output ('sum' / 'mean')"""
+    if reduce not in ("sum", "add", "mean"):
+        raise ValueError("row-partitioned aggregation supports sum and mean")
+    return _HaloAggregate.apply(h_loc, part, "sum" if reduce == "add" else reduce)

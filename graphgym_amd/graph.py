@@ -96,6 +96,14 @@ class CSRGraph:
                    None if val is None else val.to(torch.float32).contiguous(), None,
                    num_nodes, col.numel())
 
+    def row_slice(self, r0, r1):
+        """rows [r0, r1) as a rectangular operator over all columns (views of col / val, shifted rowptr):
+        the local block of a destination-row partition"""
+        e0, e1 = int(self.rowptr[r0].item()), int(self.rowptr[r1].item())
+        rp = (self.rowptr[r0:r1 + 1] - e0).contiguous()
+        return CSRGraph(rp, self.col[e0:e1], None if self.val is None else self.val[e0:e1], None,
+                        r1 - r0, e1 - e0, self.num_cols)
+
     def with_values(self, val):
         """same sparsity pattern (and plan / transpose pattern), other entry values"""
         g = CSRGraph(self.rowptr, self.col, val, self.eid, self.num_nodes, self.nnz, self.num_cols)
