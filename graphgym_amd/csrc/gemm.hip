@@ -1,0 +1,163 @@
+// The dense feature transform that follows an aggregation (K10/K11/K15), fused:
+//     out = act( P @ W  [+ Q @ W_id]  + bias )
+// i.e. the post-aggregation form of gcn_id (TfgIDLayer.py:510-523) / GCNIDConvLayer (idconv.py:152-184):
+// with P = A_hat X and Q = A_hat S X from the two-branch aggregation, this one kernel replaces two
+// GEMMs, an add, a bias add and an activation (five passes over [N, d]) of the library path.
+//
+// fp32 in, fp32 accumulate on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, the
+// only f32 MFMA rate gfx950 has: 64 FLOP/clk/SIMD).  The two products are one GEMM over the
+// concatenated K axis [P | Q] x [W ; W_id].
+//   block 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 2 x 2 MFMA tiles,
+//   K step 16, LDS double-buffered (A tile k-padded to 17 words: conflict-free 32-lane fragment reads),
+//   global -> register prefetch of tile t+1 issued before the MFMAs of tile t, written to LDS after.
+// 34 KiB LDS and ~110 VGPRs per block => 4 blocks (16 waves) per CU.
+#include "common.h"
+#include "vecio.h"
+#include <limits.h>
+
+namespace mp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16, APAD = 17;
+
+template <bool DUAL>
+__global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __restrict__ P, int64_t ldp,
+                                                             const float* __restrict__ W,
+                                                             const float* __restrict__ Q, int64_t ldq,
+                                                             const float* __restrict__ Wid,
+                                                             const float* __restrict__ bias, int act,
+                                                             float* __restrict__ out, int64_t ldo, int64_t M,
+                                                             int32_t F, int32_t d) {
+  __shared__ float As[2][BM][APAD];
+  __shared__ float Bs[2][BK][BN];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // column blocks of one row block are neighbours in dispatch order: the second reader of an A tile
+  // finds it in the Infinity Cache instead of HBM
+  const int ncb = (d + BN - 1) / BN;
+  const int64_t m0 = (int64_t)(blockIdx.x / ncb) * BM;
+  const int n0 = (int)(blockIdx.x % ncb) * BN;
+
+  // loader roles
+  const int a_row = tid >> 1;            // 0..127
+  const int a_k = (tid & 1) * 8;         // 0 or 8
+  const int b_k = tid >> 4;              // 0..15
+  const int b_n = (tid & 15) * 8;        // 0..120
+  const int64_t g_row = m0 + a_row;
+  const bool row_ok = g_row < M;
+  const int KT = DUAL ? 2 * F : F;
+
+  f32x4 ra[2], rb[2];
+  auto fetch = [&](int kt) {
+    // A: 8 consecutive k of one row, from P or (past F) from Q; F % 8 == 0 keeps a fetch inside one operand
+    const int k = kt + a_k;
+    const bool second = DUAL && k >= F;
+    const float* src = second ? Q + g_row * ldq + (k - F) : P + g_row * ldp + k;
+    const bool ok = row_ok && k < KT;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    ra[0] = ok ? *reinterpret_cast<const f32x4*>(src) : z;
+    ra[1] = ok ? *reinterpret_cast<const f32x4*>(src + 4) : z;
+    // B: 8 consecutive n of one k row of W or W_id
+    const int kb = kt + b_k;
+    const bool second_b = DUAL && kb >= F;
+    const float* wsrc = (second_b ? Wid + (int64_t)(kb - F) * d : W + (int64_t)kb * d) + n0 + b_n;
+    const bool okb = kb < KT && n0 + b_n < d;
+    rb[0] = okb ? *reinterpret_cast<const f32x4*>(wsrc) : z;
+    rb[1] = (okb && n0 + b_n + 4 < d) ? *reinterpret_cast<const f32x4*>(wsrc + 4) : z;
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      As[buf][a_row][a_k + i] = ra[0][i];
+      As[buf][a_row][a_k + 4 + i] = ra[1][i];
+    }
+    *reinterpret_cast<f32x4*>(&Bs[buf][b_k][b_n]) = rb[0];
+    *reinterpret_cast<f32x4*>(&Bs[buf][b_k][b_n + 4]) = rb[1];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  const int ntiles = (KT + BK - 1) / BK;
+  const int fr = lane & 31, fk = lane >> 5;
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) fetch((t + 1) * BK);          // in flight while the MFMAs below run
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = As[buf][wm * 64 + fr][kk + fk];
+      const float a1 = As[buf][wm * 64 + 32 + fr][kk + fk];
+      const float b0 = Bs[buf][kk + fk][wn * 64 + fr];
+      const float b1 = Bs[buf][kk + fk][wn * 64 + 32 + fr];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (t + 1 < ntiles) stash(buf ^ 1);               // the other buffer: nobody reads it this iteration
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 f32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + fr;
+    const bool col_ok = col < d;
+    const float bv = (bias != nullptr && col_ok) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        float v = acc[i][j][r] + bv;
+        if (act == MP_ACT_RELU) v = fmaxf(v, 0.f);
+        if (col_ok && row < M) out[row * ldo + col] = v;
+      }
+    }
+  }
+}
+
+static bool al16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
+
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W, const float* Q, int64_t ldq,
+                       const float* Wid, const float* bias, int act, float* out, int64_t ldo, int64_t M,
+                       int32_t F, int32_t d, mp_stream_t stream) {
+  if (M < 0 || F <= 0 || d <= 0 || !P || !W || !out || ldp < F || ldo < d) return MP_ERR_INVALID_ARG;
+  if ((Q == nullptr) != (Wid == nullptr) || (Q && ldq < F)) return MP_ERR_INVALID_ARG;
+  if (act != MP_ACT_NONE && act != MP_ACT_RELU) return MP_ERR_INVALID_ARG;
+  if (M == 0) return MP_OK;
+  // 16-byte vector loads: operand widths in multiples of 8 (F) / 4 (d) and aligned bases
+  if (F % 8 || d % 4 || ldp % 4 || (Q && ldq % 4)) return MP_ERR_UNSUPPORTED;
+  if (!al16(P) || !al16(W) || !al16(Q) || !al16(Wid)) return MP_ERR_ALIGNMENT;
+  const int64_t nblocks = ceil_div(d, BN) * ceil_div(M, BM);
+  if (nblocks >= INT32_MAX) return MP_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)nblocks);
+  hipStream_t st = as_stream(stream);
+  if (Q)
+    hipLaunchKernelGGL((dense_fused_kernel<true>), grid, dim3(kBlock), 0, st, P, ldp, W, Q, ldq, Wid, bias, act,
+                       out, ldo, M, F, d);
+  else
+    hipLaunchKernelGGL((dense_fused_kernel<false>), grid, dim3(kBlock), 0, st, P, ldp, W, Q, ldq, Wid, bias, act,
+                       out, ldo, M, F, d);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+}  // extern "C"

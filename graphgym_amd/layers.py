@@ -164,8 +164,7 @@ class GCNIDConvLayer(nn.Module, _CachedEdgesMixin):
         order = _pick_order(self.order, self.in_channels, self.out_channels)
         if order == "aggregate_first" and self._agg in ("add", "sum"):
             P, Q = ops.idgnn_aggregate(g, id, x)
-            out = torch.matmul(P, self.weight) + torch.matmul(Q, self.weight_id)
-            return out + self.bias if self.bias is not None else out
+            return ops.dense_fused(P, self.weight, Q, self.weight_id, self.bias)   # P W + Q W_id + b, one kernel
         h = _id_branch(torch.matmul(x, self.weight), x, id, self.weight_id)
         return ops.spmm(g, h, self._agg, bias=self.bias)
 
@@ -384,8 +383,7 @@ class GCNConvLayer(nn.Module):
         g = get_graph(holder, edge_index, x.size(0), loops="remaining", norm="row",
                       fill=2.0 if self.improved else 1.0, edge_weight=edge_weight)
         if _pick_order(self.order, self.in_channels, self.out_channels) == "aggregate_first":
-            out = torch.matmul(ops.spmm(g, x, "sum"), self.weight)
-            return out + self.bias if self.bias is not None else out
+            return ops.dense_fused(ops.spmm(g, x, "sum"), self.weight, bias=self.bias)
         return ops.spmm(g, torch.matmul(x, self.weight), "sum", bias=self.bias)
 
 
@@ -622,12 +620,10 @@ class IDGCN(_KerasLike):
         if order == "aggregate_first":
             if id_index is not None:
                 P, Q = ops.idgnn_aggregate(g, id_index, x)
-                h = torch.matmul(P, self.kernel) + torch.matmul(Q, self.kernel_id)
+                h = ops.dense_fused(P, self.kernel, Q, self.kernel_id, self.bias, relu=relu)
             else:
-                h = torch.matmul(ops.spmm(g, x, "sum"), self.kernel)
-            if self.bias is not None:
-                h = h + self.bias
-            return _apply_act(h, self.activation)
+                h = ops.dense_fused(ops.spmm(g, x, "sum"), self.kernel, bias=self.bias, relu=relu)
+            return h if relu else _apply_act(h, self.activation)
         h = torch.matmul(x, self.kernel)
         if id_index is not None:
             h = _id_branch(h, x, id_index, self.kernel_id)

@@ -168,6 +168,65 @@ def idgnn_aggregate(g, id_index, x, col_marked=None):
     return _IdAgg.apply(x, g, id_index.to(torch.int64), col_marked)
 
 
+def _raw_dense_fused(P, W, Q, W_id, bias, relu):
+    """out = act(P @ W [+ Q @ W_id] + bias) on the engine's MFMA kernel; None if the shapes are outside
+    what the kernel covers (the caller then composes library ops)"""
+    L = lib()
+    M, F = P.shape
+    d = W.size(1)
+    out = torch.empty((M, d), dtype=torch.float32, device=P.device)
+    Wc = W.contiguous()
+    Wi = None if W_id is None else W_id.contiguous()
+    b = None if bias is None else bias.contiguous()
+    with torch.cuda.device(P.device):
+        st = L.mp_dense_fused_f32(ptr(P), P.stride(0), ptr(Wc), ptr(Q), Q.stride(0) if Q is not None else 0,
+                                  ptr(Wi), ptr(b), _lib.ACT_RELU if relu else _lib.ACT_NONE, ptr(out),
+                                  out.stride(0), M, F, d, _stream())
+    if st in (2, 5):
+        return None
+    check(st, "mp_dense_fused_f32")
+    return out
+
+
+class _DenseFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, P, W, Q, W_id, bias, relu):
+        Pc = _f32c(P, "P")
+        Qc = None if Q is None else _f32c(Q, "Q")
+        out = _raw_dense_fused(Pc, W.detach(), Qc, None if W_id is None else W_id.detach(),
+                               None if bias is None else bias.detach(), relu)
+        if out is None:     # shape outside the fused kernel: library GEMMs
+            out = Pc @ W.detach()
+            if Qc is not None:
+                out = out + Qc @ W_id.detach()
+            if bias is not None:
+                out = out + bias.detach()
+            if relu:
+                out = torch.relu(out)
+        ctx.relu = relu
+        ctx.save_for_backward(Pc, W, Qc, W_id, out if relu else None)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        P, W, Q, W_id, out = ctx.saved_tensors
+        if ctx.relu:
+            g = g * (out > 0)
+        g = g.contiguous()
+        dP = g @ W.t() if ctx.needs_input_grad[0] else None
+        dW = P.t() @ g if ctx.needs_input_grad[1] else None
+        dQ = g @ W_id.t() if (Q is not None and ctx.needs_input_grad[2]) else None
+        dWid = Q.t() @ g if (Q is not None and ctx.needs_input_grad[3]) else None
+        db = g.sum(0) if ctx.has_bias else None
+        return dP, dW, dQ, dWid, db, None
+
+
+def dense_fused(P, W, Q=None, W_id=None, bias=None, relu=False):
+    """act(P @ W [+ Q @ W_id] + bias) in one kernel (mp_dense_fused_f32); gradients through library GEMMs"""
+    return _DenseFused.apply(P, W, Q, W_id, bias, bool(relu))
+
+
 class _IndexAddRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, id_index, u):

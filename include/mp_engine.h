@@ -221,6 +221,22 @@ int mp_spmm_max_bwd_f32(const int32_t* col, const float* val, const int32_t* arg
                         float* dX, int64_t ldx, mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
+ * Dense transform after the aggregation, fused (K10 / K11 / K15):       *
+ *   out = act( P @ W [+ Q @ W_id] + bias )                              *
+ * P, Q [M, F] (ldp, ldq), W, W_id [F, d] row-major contiguous, bias [d] *
+ * or NULL, out [M, d] (ldo).  Q == W_id == NULL gives the single        *
+ * product.  fp32 on the matrix cores (v_mfma_f32_32x32x2_f32).          *
+ * Replaces x @ kernel, x_id @ kernel_id, scatter-add, + bias, activation *
+ * of gcn_id in its post-aggregation form (TfgIDLayer.py:510-523;        *
+ * idconv.py:152-184).  Needs F % 8 == 0, d % 4 == 0, 16-byte aligned    *
+ * operands (MP_ERR_UNSUPPORTED / MP_ERR_ALIGNMENT otherwise).           *
+ * ------------------------------------------------------------------ */
+int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W,
+                       const float* Q, int64_t ldq, const float* W_id,
+                       const float* bias, int act, float* out, int64_t ldo,
+                       int64_t M, int32_t F, int32_t d, mp_stream_t stream);
+
+/* ------------------------------------------------------------------ *
  * Identity-row update (K10): H[id[k], :] += U[k, :]                   *
  * replaces tf.tensor_scatter_nd_add (TfgIDLayer.py:107,165,330,515)   *
  * and x.index_add_(0, id, x_id) (idconv.py:67,155,251,310,375).       *

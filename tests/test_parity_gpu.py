@@ -488,3 +488,36 @@ def test_randomised_graphs_under_a_tiny_plan(dev):
             close(Q, R.coo_aggregate(ei[1], ei[0], w.double(), (x * sel).double(), N, "sum"))
     finally:
         assert L.mp_spmm_plan_config(320, 4, 1024, 256) == 0
+
+
+@pytest.mark.parametrize("M,F,d", [(1, 8, 4), (127, 16, 64), (128, 64, 128), (129, 72, 100), (1000, 256, 256),
+                                   (777, 264, 132), (300, 128, 512), (4100, 8, 260)])
+@pytest.mark.parametrize("dual", [False, True])
+def test_dense_fused_mfma_kernel(dev, M, F, d, dual):
+    """act(P @ W [+ Q @ W_id] + bias) on the f32 MFMA kernel vs float64 on the host (forward), and its
+    autograd (library GEMMs) vs torch's own autograd of the unfused expression"""
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(M + F + d)
+    P, Q = torch.randn(M, F, generator=g), torch.randn(M, F, generator=g)
+    W, Wi = torch.randn(F, d, generator=g) / F ** 0.5, torch.randn(F, d, generator=g) / F ** 0.5
+    b = torch.randn(d, generator=g)
+    ref = P.double() @ W.double() + b.double()
+    if dual:
+        ref = ref + Q.double() @ Wi.double()
+    ref = torch.relu(ref)
+    args = [t.to(dev).requires_grad_(True) for t in (P, W, Q, Wi, b)]
+    out = ops.dense_fused(args[0], args[1], args[2] if dual else None, args[3] if dual else None, args[4], relu=True)
+    close(out, ref, 1e-5)
+    dy = torch.randn(M, d, generator=g)
+    out.backward(dy.to(dev))
+    refs = [t.clone().requires_grad_(True) for t in (P, W, Q, Wi, b)]
+    r = refs[0] @ refs[1] + refs[4]
+    if dual:
+        r = r + refs[2] @ refs[3]
+    torch.relu(r).backward(dy)
+    for a, rr, name in zip(args, refs, "P W Q Wid b".split()):
+        if not dual and name in ("Q", "Wid"):
+            continue
+        close(a.grad, rr.grad, 2e-4)
+    # the raw kernel really ran for these shapes (no library fallback)
+    assert ops._raw_dense_fused(P.to(dev), W.to(dev), None, None, None, False) is not None
