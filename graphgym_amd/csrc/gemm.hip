@@ -19,9 +19,11 @@ namespace mp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16, APAD = 17;
+constexpr int BM = 128, BK = 16, APAD = 17;
 
-template <bool DUAL>
+// TN = 32-column MFMA tiles per wave along N: block tile 128 x (64 * TN).  TN = 4 (BN = 256) reads every
+// A row once when d <= 256 and issues 8 MFMAs per 6 LDS fragment reads; TN = 2 serves narrower outputs.
+template <bool DUAL, int TN>
 __global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __restrict__ P, int64_t ldp,
                                                              const float* __restrict__ W,
                                                              const float* __restrict__ Q, int64_t ldq,
@@ -29,6 +31,8 @@ __global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __rest
                                                              const float* __restrict__ bias, int act,
                                                              float* __restrict__ out, int64_t ldo, int64_t M,
                                                              int32_t F, int32_t d) {
+  constexpr int BN = 64 * TN;
+  constexpr int NB4 = BN / 64;           // float4 loads of B per thread per tile
   __shared__ float As[2][BM][APAD];
   __shared__ float Bs[2][BK][BN];
   const int tid = threadIdx.x;
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __rest
   const int wm = wave >> 1, wn = wave & 1;
   // column blocks of one row block are neighbours in dispatch order: the second reader of an A tile
   // finds it in the Infinity Cache instead of HBM
-  const int ncb = (d + BN - 1) / BN;
+  const int ncb = (d + BN - 1) / BN;   // (BN declared below is a compile-time constant of this instantiation)
   const int64_t m0 = (int64_t)(blockIdx.x / ncb) * BM;
   const int n0 = (int)(blockIdx.x % ncb) * BN;
 
@@ -45,12 +49,12 @@ __global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __rest
   const int a_row = tid >> 1;            // 0..127
   const int a_k = (tid & 1) * 8;         // 0 or 8
   const int b_k = tid >> 4;              // 0..15
-  const int b_n = (tid & 15) * 8;        // 0..120
+  const int b_n = (tid & 15) * (4 * NB4);  // first of this thread's 4*NB4 consecutive columns
   const int64_t g_row = m0 + a_row;
   const bool row_ok = g_row < M;
   const int KT = DUAL ? 2 * F : F;
 
-  f32x4 ra[2], rb[2];
+  f32x4 ra[2], rb[NB4];
   auto fetch = [&](int kt) {
     // A: 8 consecutive k of one row, from P or (past F) from Q; F % 8 == 0 keeps a fetch inside one operand
     const int k = kt + a_k;
@@ -64,9 +68,9 @@ __global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __rest
     const int kb = kt + b_k;
     const bool second_b = DUAL && kb >= F;
     const float* wsrc = (second_b ? Wid + (int64_t)(kb - F) * d : W + (int64_t)kb * d) + n0 + b_n;
-    const bool okb = kb < KT && n0 + b_n < d;
-    rb[0] = okb ? *reinterpret_cast<const f32x4*>(wsrc) : z;
-    rb[1] = (okb && n0 + b_n + 4 < d) ? *reinterpret_cast<const f32x4*>(wsrc + 4) : z;
+#pragma unroll
+    for (int q = 0; q < NB4; ++q)
+      rb[q] = (kb < KT && n0 + b_n + 4 * q < d) ? *reinterpret_cast<const f32x4*>(wsrc + 4 * q) : z;
   };
   auto stash = [&](int buf) {
 #pragma unroll
@@ -74,15 +78,15 @@ __global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __rest
       As[buf][a_row][a_k + i] = ra[0][i];
       As[buf][a_row][a_k + 4 + i] = ra[1][i];
     }
-    *reinterpret_cast<f32x4*>(&Bs[buf][b_k][b_n]) = rb[0];
-    *reinterpret_cast<f32x4*>(&Bs[buf][b_k][b_n + 4]) = rb[1];
+#pragma unroll
+    for (int q = 0; q < NB4; ++q) *reinterpret_cast<f32x4*>(&Bs[buf][b_k][b_n + 4 * q]) = rb[q];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -98,12 +102,14 @@ __global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __rest
     for (int kk = 0; kk < BK; kk += 2) {
       const float a0 = As[buf][wm * 64 + fr][kk + fk];
       const float a1 = As[buf][wm * 64 + 32 + fr][kk + fk];
-      const float b0 = Bs[buf][kk + fk][wn * 64 + fr];
-      const float b1 = Bs[buf][kk + fk][wn * 64 + 32 + fr];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float bf[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][kk + fk][wn * (32 * TN) + j * 32 + fr];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[j], acc[1][j], 0, 0, 0);
+      }
     }
     if (t + 1 < ntiles) stash(buf ^ 1);               // the other buffer: nobody reads it this iteration
     __syncthreads();
@@ -111,8 +117,8 @@ __global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __rest
 
   // epilogue: C/D layout of the 32x32 f32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + fr;
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (32 * TN) + j * 32 + fr;
     const bool col_ok = col < d;
     const float bv = (bias != nullptr && col_ok) ? bias[col] : 0.f;
 #pragma unroll
@@ -129,12 +135,19 @@ __global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __rest
 }
 
 static bool al16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
+static int g_dense_tn = 0;   // 0 = by output width; 2 forces the 128-column tile (tuning knob)
 
 }  // namespace mp
 
 using namespace mp;
 
 extern "C" {
+
+int mp_dense_config(int force_tn) {
+  if (force_tn != 0 && force_tn != 2) return MP_ERR_INVALID_ARG;
+  g_dense_tn = force_tn;
+  return MP_OK;
+}
 
 int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W, const float* Q, int64_t ldq,
                        const float* Wid, const float* bias, int act, float* out, int64_t ldo, int64_t M,
@@ -146,16 +159,18 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W, const float*
   // 16-byte vector loads: operand widths in multiples of 8 (F) / 4 (d) and aligned bases
   if (F % 8 || d % 4 || ldp % 4 || (Q && ldq % 4)) return MP_ERR_UNSUPPORTED;
   if (!al16(P) || !al16(W) || !al16(Q) || !al16(Wid)) return MP_ERR_ALIGNMENT;
-  const int64_t nblocks = ceil_div(d, BN) * ceil_div(M, BM);
+  const int tn = (d > 128 && g_dense_tn != 2) ? 4 : 2;
+  const int bn = 64 * tn;
+  const int64_t nblocks = ceil_div(d, bn) * ceil_div(M, BM);
   if (nblocks >= INT32_MAX) return MP_ERR_UNSUPPORTED;
   dim3 grid((unsigned)nblocks);
   hipStream_t st = as_stream(stream);
-  if (Q)
-    hipLaunchKernelGGL((dense_fused_kernel<true>), grid, dim3(kBlock), 0, st, P, ldp, W, Q, ldq, Wid, bias, act,
-                       out, ldo, M, F, d);
-  else
-    hipLaunchKernelGGL((dense_fused_kernel<false>), grid, dim3(kBlock), 0, st, P, ldp, W, Q, ldq, Wid, bias, act,
-                       out, ldo, M, F, d);
+#define MP_DENSE(DUALV, TNV)                                                                             \
+  hipLaunchKernelGGL((dense_fused_kernel<DUALV, TNV>), grid, dim3(kBlock), 0, st, P, ldp, W, Q, ldq, Wid, bias, \
+                     act, out, ldo, M, F, d)
+  if (Q) { if (tn == 4) MP_DENSE(true, 4); else MP_DENSE(true, 2); }
+  else { if (tn == 4) MP_DENSE(false, 4); else MP_DENSE(false, 2); }
+#undef MP_DENSE
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
