@@ -21,10 +21,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BK = 16, APAD = 17;
 
-// TN = 32-column MFMA tiles per wave along N: block tile 128 x (64 * TN).  TN = 4 (BN = 256) reads every
-// A row once when d <= 256 and issues 8 MFMAs per 6 LDS fragment reads; TN = 2 serves narrower outputs.
+// TN = 32-column MFMA tiles per wave along N: block tile 128 x (64 * TN).  TN = 2 (128 columns, 3 waves per
+// SIMD) is the default; TN = 4 (256 columns: every A row read once at d <= 256) needs 297 registers, runs
+// one wave per SIMD and measured 25 % slower — kept behind mp_dense_config(4) for the record.
 template <bool DUAL, int TN>
-__global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __restrict__ P, int64_t ldp,
+__global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(const float* __restrict__ P, int64_t ldp,
                                                              const float* __restrict__ W,
                                                              const float* __restrict__ Q, int64_t ldq,
                                                              const float* __restrict__ Wid,
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void dense_fused_kernel(const float* __rest
 }
 
 static bool al16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
-static int g_dense_tn = 0;   // 0 = by output width; 2 forces the 128-column tile (tuning knob)
+static int g_dense_tn = 0;   // 0 / 2 = 128-column tile (default); 4 = 256-column tile when d > 128 (tuning knob)
 
 }  // namespace mp
 
@@ -144,7 +145,7 @@ using namespace mp;
 extern "C" {
 
 int mp_dense_config(int force_tn) {
-  if (force_tn != 0 && force_tn != 2) return MP_ERR_INVALID_ARG;
+  if (force_tn != 0 && force_tn != 2 && force_tn != 4) return MP_ERR_INVALID_ARG;
   g_dense_tn = force_tn;
   return MP_OK;
 }
@@ -159,7 +160,7 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W, const float*
   // 16-byte vector loads: operand widths in multiples of 8 (F) / 4 (d) and aligned bases
   if (F % 8 || d % 4 || ldp % 4 || (Q && ldq % 4)) return MP_ERR_UNSUPPORTED;
   if (!al16(P) || !al16(W) || !al16(Q) || !al16(Wid)) return MP_ERR_ALIGNMENT;
-  const int tn = (d > 128 && g_dense_tn != 2) ? 4 : 2;
+  const int tn = (d > 128 && g_dense_tn == 4) ? 4 : 2;   // the 256-column tile fits one wave per SIMD only: slower
   const int bn = 64 * tn;
   const int64_t nblocks = ceil_div(d, bn) * ceil_div(M, BM);
   if (nblocks >= INT32_MAX) return MP_ERR_UNSUPPORTED;

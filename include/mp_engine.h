@@ -231,7 +231,7 @@ int mp_spmm_max_bwd_f32(const int32_t* col, const float* val, const int32_t* arg
  * idconv.py:152-184).  Needs F % 8 == 0, d % 4 == 0, 16-byte aligned    *
  * operands (MP_ERR_UNSUPPORTED / MP_ERR_ALIGNMENT otherwise).           *
  * ------------------------------------------------------------------ */
-/* tuning knob: 0 = tile width by output width (256 columns when d > 128), 2 = force 128 columns */
+/* tuning knob: 0 / 2 = 128-column block tile (default), 4 = 256-column tile when d > 128 */
 int mp_dense_config(int force_tn);
 int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W,
                        const float* Q, int64_t ldq, const float* W_id,
