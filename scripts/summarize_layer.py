@@ -19,11 +19,12 @@ def avg(kname, counter):
         if kname in k and c == counter:
             return sum(v) / len(v)
     return None
-gemm = next(k for k in stats if k.startswith("Cijk_"))
+gemm = next((k for k in stats if "dense_fused_kernel" in k), None) or next(k for k in stats if k.startswith("Cijk_"))
+gkey = "dense_fused_kernel" if "dense_fused_kernel" in gemm else "Cijk_"
 agg = next(k for k in stats if "agg_rows_kernel" in k)
 gemm_ns = stats[gemm][1]
-flops = avg("Cijk_", "SQ_INSTS_VALU_MFMA_MOPS_F32") * 512
-busy, gui = avg("Cijk_", "SQ_VALU_MFMA_BUSY_CYCLES"), avg("Cijk_", "GRBM_GUI_ACTIVE")
+flops = avg(gkey, "SQ_INSTS_VALU_MFMA_MOPS_F32") * 512
+busy, gui = avg(gkey, "SQ_VALU_MFMA_BUSY_CYCLES"), avg(gkey, "GRBM_GUI_ACTIVE")
 rec = {
     "workload": f"one GCN layer, aggregate then transform, BA({n},5)+loops, d={d}, fp32",
     "aggregation_kernel": {"name": agg, "avg_ns": stats[agg][1], "mfma_instructions": avg("agg_rows", "SQ_INSTS_VALU_MFMA_F32")},
@@ -34,5 +35,5 @@ rec = {
                     "note": "MfmaUtil = MFMA busy cycles / (GUI-active cycles per XCD x 1024 SIMDs), the rocprofv3 derived-counter formula; "
                             "counters collected in separate --pmc passes"},
 }
-json.dump(rec, open(os.path.join(ROOT, "profiles", f"{tag}_layer.json"), "w"), indent=1)
+json.dump(rec, open(os.path.join(ROOT, "profiles", f"{tag}_layer.json" if len(sys.argv) < 4 else sys.argv[3]), "w"), indent=1)
 print(json.dumps(rec, indent=1))
