@@ -165,7 +165,7 @@ class GCNIDConvLayer(nn.Module, _CachedEdgesMixin):
         if order == "aggregate_first" and self._agg in ("add", "sum"):
             P, Q = ops.idgnn_aggregate(g, id, x)
             return ops.dense_fused(P, self.weight, Q, self.weight_id, self.bias)   # P W + Q W_id + b, one kernel
-        h = _id_branch(torch.matmul(x, self.weight), x, id, self.weight_id)
+        h = _id_branch(ops.dense_fused(x, self.weight), x, id, self.weight_id)
         return ops.spmm(g, h, self._agg, bias=self.bias)
 
     def __repr__(self):
@@ -214,8 +214,8 @@ class GeneralConvLayer(nn.Module, _CachedEdgesMixin):
         if self.self_msg not in ('none', 'add', 'concat'):
             raise ValueError('self_msg {} not defined'.format(self.self_msg))
         if self.self_msg == 'concat':
-            x_self = torch.matmul(x, self.weight_self)
-        h = torch.matmul(x, self.weight)
+            x_self = ops.dense_fused(x, self.weight_self)
+        h = ops.dense_fused(x, self.weight)
         if self.normalize:
             g = self._graph(holder, edge_index, x.size(0), edge_weight, loops="remaining", norm="col",
                             fill=2.0 if self.improved else 1.0)
@@ -314,7 +314,7 @@ class GATIDConvLayer(nn.Module):
 
     def forward(self, x, edge_index, id, size=None, holder=None):
         g = get_graph(holder, edge_index, x.size(0), loops="remove_add")
-        h = torch.matmul(x, self.weight)
+        h = ops.dense_fused(x, self.weight)
         if id is not None:
             h = _id_branch(h, x, id, self.weight_id)
         return self._attend(g, h)
@@ -384,7 +384,7 @@ class GCNConvLayer(nn.Module):
                       fill=2.0 if self.improved else 1.0, edge_weight=edge_weight)
         if _pick_order(self.order, self.in_channels, self.out_channels) == "aggregate_first":
             return ops.dense_fused(ops.spmm(g, x, "sum"), self.weight, bias=self.bias)
-        return ops.spmm(g, torch.matmul(x, self.weight), "sum", bias=self.bias)
+        return ops.spmm(g, ops.dense_fused(x, self.weight), "sum", bias=self.bias)
 
 
 class SAGEConvLayer(nn.Module):
@@ -624,7 +624,7 @@ class IDGCN(_KerasLike):
             else:
                 h = ops.dense_fused(ops.spmm(g, x, "sum"), self.kernel, bias=self.bias, relu=relu)
             return h if relu else _apply_act(h, self.activation)
-        h = torch.matmul(x, self.kernel)
+        h = ops.dense_fused(x, self.kernel)
         if id_index is not None:
             h = _id_branch(h, x, id_index, self.kernel_id)
         h = ops.spmm(g, h, "sum", bias=self.bias, relu=relu)      # bias + activation fused (:519-523)
@@ -758,9 +758,13 @@ class IDGAT(_KerasLike):
         self._maybe_build(x)
         H = self.num_heads
         g = get_graph(holder, edge_index, x.size(0), dst_row=0, loops="add")
-        Q = _apply_act(torch.matmul(x, self.query_kernel) + self.query_bias, self.query_activation)
-        K = _apply_act(torch.matmul(x, self.key_kernel) + self.key_bias, self.key_activation)
-        V = torch.matmul(x, self.kernel)
+        def proj(kernel, bias, act):   # act(x @ kernel + bias) in one kernel when act is relu / None
+            if act is None or _is_relu(act):
+                return ops.dense_fused(x, kernel, bias=bias, relu=act is not None)
+            return _apply_act(ops.dense_fused(x, kernel, bias=bias), act)
+        Q = proj(self.query_kernel, self.query_bias, self.query_activation)
+        K = proj(self.key_kernel, self.key_bias, self.key_activation)
+        V = ops.dense_fused(x, self.kernel)
         if id_index is not None:
             V = _id_branch(V, x, id_index, self.kernel_id)
         scale = 1.0 / math.sqrt(self.attention_units // H)

@@ -214,9 +214,13 @@ class _DenseFused(torch.autograd.Function):
         if ctx.relu:
             g = g * (out > 0)
         g = g.contiguous()
-        dP = g @ W.t() if ctx.needs_input_grad[0] else None
+
+        def times_wt(Wm):   # g @ Wm^T on the engine's kernel when the shape allows, else the library
+            r = _raw_dense_fused(g, Wm.detach().t().contiguous(), None, None, None, False)
+            return r if r is not None else g @ Wm.t()
+        dP = times_wt(W) if ctx.needs_input_grad[0] else None
         dW = P.t() @ g if ctx.needs_input_grad[1] else None
-        dQ = g @ W_id.t() if (Q is not None and ctx.needs_input_grad[2]) else None
+        dQ = times_wt(W_id) if (Q is not None and ctx.needs_input_grad[2]) else None
         dWid = Q.t() @ g if (Q is not None and ctx.needs_input_grad[3]) else None
         db = g.sum(0) if ctx.has_bias else None
         return dP, dW, dQ, dWid, db, None
