@@ -104,6 +104,20 @@ class CSRGraph:
         return CSRGraph(rp, self.col[e0:e1], None if self.val is None else self.val[e0:e1], None,
                         r1 - r0, e1 - e0, self.num_cols)
 
+    def select_rows(self, rows):
+        """the rows `rows` (LongTensor, any order) as a rectangular operator [len(rows), num_cols]"""
+        rows = rows.to(torch.int64)
+        rp64 = self.rowptr.to(torch.int64)
+        start = rp64.index_select(0, rows)
+        deg = rp64.index_select(0, rows + 1) - start
+        rp = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(deg, 0, out=rp[1:])
+        total = int(rp[-1].item())
+        idx = torch.arange(total, device=self.device) + torch.repeat_interleave(start - rp[:-1], deg)
+        return CSRGraph(rp.to(torch.int32), self.col[idx].contiguous(),
+                        None if self.val is None else self.val[idx].contiguous(), None,
+                        rows.numel(), total, self.num_cols)
+
     def with_values(self, val):
         """same sparsity pattern (and plan / transpose pattern), other entry values"""
         g = CSRGraph(self.rowptr, self.col, val, self.eid, self.num_nodes, self.nnz, self.num_cols)

@@ -154,9 +154,11 @@ class _IdAgg(torch.autograd.Function):
         (id_index,) = ctx.saved_tensors
         gt = ctx.g.transpose()
         dx, _ = _raw_spmm(gt, dP.contiguous(), _lib.SUM)
-        # Q = A S x  =>  dx[id] += (A^T dQ)[id]
-        t, _ = _raw_spmm(gt, dQ.contiguous(), _lib.SUM)
-        dx.index_add_(0, id_index, t.index_select(0, id_index))
+        # Q = A S x  =>  dx[id] += (A^T dQ)[id]: only the identity nodes' rows of A^T are needed, an
+        # aggregation over their out-edges alone (a [n_id, N] operator), not a second full pass
+        sub = gt.select_rows(id_index)
+        t, _ = _raw_spmm(sub, dQ.contiguous(), _lib.SUM)
+        dx.index_add_(0, id_index, t)
         return dx, None, None, None
 
 
