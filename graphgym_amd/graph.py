@@ -105,7 +105,17 @@ class CSRGraph:
                         r1 - r0, e1 - e0, self.num_cols)
 
     def select_rows(self, rows):
-        """the rows `rows` (LongTensor, any order) as a rectangular operator [len(rows), num_cols]"""
+        """the rows `rows` (LongTensor, any order) as a rectangular operator [len(rows), num_cols];
+        cached per index tensor (a batch's node_id_index is the same tensor every step)"""
+        stamp = (rows.data_ptr(), rows.numel(), rows._version)
+        cache = self.__dict__.setdefault("_row_subsets", {})
+        if stamp not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[stamp] = self._select_rows(rows)
+        return cache[stamp]
+
+    def _select_rows(self, rows):
         rows = rows.to(torch.int64)
         rp64 = self.rowptr.to(torch.int64)
         start = rp64.index_select(0, rows)
