@@ -114,7 +114,33 @@ def idgcn_step(d=128, f_in=1):
          edges=int(ei.size(1)), gpu_ms_per_step=t * 1e3, cpu_oracle_ms_per_step=tc * 1e3, speedup=tc / t,
          cpu_threads=torch.get_num_threads())
 
+def cora_like_step(d=128, centres=128, radius=2):
+    """config C3 shape with a synthetic stand-in for Cora (the dataset is not available offline):
+    N = 2708, 10556 directed edges, F = 1433, 7 classes; ID-GCN Full on a batch of 128 ego nets, radius 2."""
+    n, f_in, classes = 2708, 1433, 7
+    G = nx.gnm_random_graph(n, 5278, seed=3)
+    e = np.array(list(G.edges()), dtype=np.int64)
+    base_ei = torch.from_numpy(np.concatenate([e, e[:, ::-1]]).T.copy()).to(dev)
+    base = ga.CSRGraph.from_edge_index(base_ei, n)
+    gen = torch.Generator().manual_seed(0)
+    feats = (torch.rand(n, f_in, generator=gen) < 0.0127).float().to(dev)       # sparse bag-of-words density of Cora
+    labels_all = torch.randint(0, classes, (n,), generator=gen).to(dev)
+    cen = torch.randperm(n, generator=gen)[:centres].to(dev)
+    t_ego, (ei, orig, ids, _) = sync_time(lambda: ego_batch(base, cen, radius))
+    x = feats[orig]
+    labels = labels_all[cen]
+    batch = H.Batch(edge_index=ei, node_id_index=ids)
+    model = H.TfgNodeModel("idgcn", f_in, d, classes).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    def fl():
+        return H.tfg_loss(model([x, ei, ids], holder=batch), ids, labels, model.kernel_parameters())
+    t, _ = sync_time(lambda: H.train_step(model, opt, fl), iters=20)
+    emit(what="idgcn_tf step, Cora-like synthetic (N=2708, E=10556, F=1433), 128 ego nets radius 2", d=d,
+         batch_nodes=int(orig.numel()), batch_edges=int(ei.size(1)), ego_build_ms=t_ego * 1e3, gpu_ms_per_step=t * 1e3)
+
+
 if __name__ == "__main__":
+    cora_like_step()
     csr_build(1_000_000)
     csr_build(10_000_000)
     ego_large()
