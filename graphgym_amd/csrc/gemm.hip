@@ -135,6 +135,113 @@ __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(co
   }
 }
 
+
+// Weight gradient of the transform: dW[F, d] = P^T g = sum_m P[m, :]^T g[m, :]  (the reduction runs over
+// the node axis).  Both MFMA operands are plain row tiles with k = node index — A[i = f][k = m] = P[m][f],
+// B[k = m][j] = g[m][j] — so the LDS tiles are straight copies of global rows and every fragment read is
+// 32 consecutive words.  Split-K over nodes: a block owns `chunk` rows and one 128 x 128 output tile and
+// writes its partial to a slab; a second kernel adds the slabs in chunk order (bitwise reproducible, unlike
+// float atomics).
+template <int DUMMY>
+__global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __restrict__ P, int64_t ldp,
+                                                                const float* __restrict__ G, int64_t ldg,
+                                                                int64_t M, int32_t F, int32_t d, int64_t chunk,
+                                                                float* __restrict__ slabs) {
+  constexpr int BT = 128;                 // output tile 128 (f) x 128 (d)
+  __shared__ float Ps[2][BK][BT];
+  __shared__ float Gs[2][BK][BT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tf = (F + BT - 1) / BT, td = (d + BT - 1) / BT;
+  const int tile = blockIdx.x % (tf * td);
+  const int64_t c = blockIdx.x / (tf * td);
+  const int f0 = (tile / td) * BT, d0 = (tile % td) * BT;
+  const int64_t mb = c * chunk;
+  const int64_t me = mb + chunk < M ? mb + chunk : M;
+
+  const int l_row = tid >> 4;              // 0..15: node row inside the tile
+  const int l_col = (tid & 15) * 8;        // 8 consecutive columns
+  f32x4 rp[2], rg[2];
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int64_t m0) {
+    const int64_t m = m0 + l_row;
+    const bool ok = m < me;
+    const float* ps = P + m * ldp + f0 + l_col;
+    const float* gs = G + m * ldg + d0 + l_col;
+    rp[0] = (ok && f0 + l_col < F) ? *reinterpret_cast<const f32x4*>(ps) : z;
+    rp[1] = (ok && f0 + l_col + 4 < F) ? *reinterpret_cast<const f32x4*>(ps + 4) : z;
+    rg[0] = (ok && d0 + l_col < d) ? *reinterpret_cast<const f32x4*>(gs) : z;
+    rg[1] = (ok && d0 + l_col + 4 < d) ? *reinterpret_cast<const f32x4*>(gs + 4) : z;
+  };
+  auto stash = [&](int buf) {
+    *reinterpret_cast<f32x4*>(&Ps[buf][l_row][l_col]) = rp[0];
+    *reinterpret_cast<f32x4*>(&Ps[buf][l_row][l_col + 4]) = rp[1];
+    *reinterpret_cast<f32x4*>(&Gs[buf][l_row][l_col]) = rg[0];
+    *reinterpret_cast<f32x4*>(&Gs[buf][l_row][l_col + 4]) = rg[1];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fk = lane >> 5;
+  const int64_t ntiles = (me - mb + BK - 1) / BK;
+  if (ntiles > 0) {
+    fetch(mb);
+    stash(0);
+  }
+  __syncthreads();
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < ntiles) fetch(mb + (t + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = Ps[buf][kk + fk][wm * 64 + fr];
+      const float a1 = Ps[buf][kk + fk][wm * 64 + 32 + fr];
+      const float b0 = Gs[buf][kk + fk][wn * 64 + fr];
+      const float b1 = Gs[buf][kk + fk][wn * 64 + 32 + fr];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (t + 1 < ntiles) stash(buf ^ 1);
+    __syncthreads();
+  }
+  float* slab = slabs + c * (int64_t)F * d;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = d0 + wn * 64 + j * 32 + fr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = f0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (row < F && col < d) slab[(int64_t)row * d + col] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t n_slab,
+                                                             int64_t elems, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int64_t c = 0; c < n_slab; ++c) acc += slabs[c * elems + i];
+    out[i] = acc;
+  }
+}
+
+static int64_t wgrad_chunk(int64_t M) {
+  // enough chunks to fill the chip with 128 x 128 tiles, few enough that the slab pass stays small
+  int64_t chunk = 4096;
+  while (chunk < 65536 && ceil_div(M, chunk) > 1024) chunk *= 2;
+  return chunk;
+}
+
 static bool al16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
 static int g_dense_tn = 0;   // 0 / 2 = 128-column tile (default); 4 = 256-column tile when d > 128 (tuning knob)
 
@@ -172,6 +279,37 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W, const float*
   if (Q) { if (tn == 4) MP_DENSE(true, 4); else MP_DENSE(true, 2); }
   else { if (tn == 4) MP_DENSE(false, 4); else MP_DENSE(false, 2); }
 #undef MP_DENSE
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+int mp_dense_wgrad_ws_bytes(int64_t M, int32_t F, int32_t d, size_t* bytes_host) {
+  if (!bytes_host || M < 0 || F <= 0 || d <= 0) return MP_ERR_INVALID_ARG;
+  *bytes_host = (size_t)ceil_div(M > 0 ? M : 1, wgrad_chunk(M)) * (size_t)F * d * 4;
+  return MP_OK;
+}
+
+int mp_dense_wgrad_f32(const float* P, int64_t ldp, const float* G, int64_t ldg, int64_t M, int32_t F,
+                       int32_t d, float* dW, void* ws, size_t ws_bytes, mp_stream_t stream) {
+  if (M < 0 || F <= 0 || d <= 0 || !dW || (M > 0 && (!P || !G)) || ldp < F || ldg < d) return MP_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  if (M == 0) {
+    MP_HIP(hipMemsetAsync(dW, 0, (size_t)F * d * 4, st));
+    return MP_OK;
+  }
+  if (F % 4 || d % 4 || ldp % 4 || ldg % 4) return MP_ERR_UNSUPPORTED;
+  if (!al16(P) || !al16(G)) return MP_ERR_ALIGNMENT;
+  const int64_t chunk = wgrad_chunk(M);
+  const int64_t n_chunk = ceil_div(M, chunk);
+  const size_t need = (size_t)n_chunk * F * d * 4;
+  if (!ws || ws_bytes < need) return MP_ERR_WORKSPACE;
+  const int64_t tiles = ceil_div(F, 128) * ceil_div(d, 128);
+  if (tiles * n_chunk >= INT32_MAX) return MP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((dense_wgrad_kernel<0>), dim3((unsigned)(tiles * n_chunk)), dim3(kBlock), 0, st, P, ldp, G, ldg,
+                     M, F, d, chunk, (float*)ws);
+  MP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)F * d)), dim3(kBlock), 0, st, (const float*)ws,
+                     n_chunk, (int64_t)F * d, dW);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

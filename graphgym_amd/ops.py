@@ -190,6 +190,24 @@ def _raw_dense_fused(P, W, Q, W_id, bias, relu):
     return out
 
 
+def _raw_dense_wgrad(P, G):
+    """P^T @ G on the engine's split-K MFMA kernel (None when the shape is outside it)"""
+    L = lib()
+    M, F = P.shape
+    d = G.size(1)
+    out = torch.empty((F, d), dtype=torch.float32, device=P.device)
+    with torch.cuda.device(P.device):
+        nb = C.c_size_t(0)
+        check(L.mp_dense_wgrad_ws_bytes(M, F, d, C.byref(nb)))
+        ws = torch.empty(max(nb.value, 1), dtype=torch.uint8, device=P.device)
+        st = L.mp_dense_wgrad_f32(ptr(P), P.stride(0), ptr(G), G.stride(0), M, F, d, ptr(out), ptr(ws), nb.value,
+                                  _stream())
+    if st in (2, 5):
+        return None
+    check(st, "mp_dense_wgrad_f32")
+    return out
+
+
 class _DenseFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, P, W, Q, W_id, bias, relu):
@@ -220,10 +238,13 @@ class _DenseFused(torch.autograd.Function):
         def times_wt(Wm):   # g @ Wm^T on the engine's kernel when the shape allows, else the library
             r = _raw_dense_fused(g, Wm.detach().t().contiguous(), None, None, None, False)
             return r if r is not None else g @ Wm.t()
+        def wgrad(Xm):      # Xm^T @ g
+            r = _raw_dense_wgrad(Xm, g)
+            return r if r is not None else Xm.t() @ g
         dP = times_wt(W) if ctx.needs_input_grad[0] else None
-        dW = P.t() @ g if ctx.needs_input_grad[1] else None
+        dW = wgrad(P) if ctx.needs_input_grad[1] else None
         dQ = times_wt(W_id) if (Q is not None and ctx.needs_input_grad[2]) else None
-        dWid = Q.t() @ g if (Q is not None and ctx.needs_input_grad[3]) else None
+        dWid = wgrad(Q) if (Q is not None and ctx.needs_input_grad[3]) else None
         db = g.sum(0) if ctx.has_bias else None
         return dP, dW, dQ, dWid, db, None
 

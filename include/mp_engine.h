@@ -238,6 +238,14 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W,
                        const float* bias, int act, float* out, int64_t ldo,
                        int64_t M, int32_t F, int32_t d, mp_stream_t stream);
 
+/* weight gradient of the transform: dW [F, d] = P^T @ G with P [M, F], G [M, d] (backward of K11 under
+ * loss.backward(), graphgym/train.py:24).  Split over the node axis into slabs in `ws`
+ * (mp_dense_wgrad_ws_bytes), summed in a fixed order: bitwise reproducible.  F % 4 == 0, d % 4 == 0. */
+int mp_dense_wgrad_ws_bytes(int64_t M, int32_t F, int32_t d, size_t* bytes_host);
+int mp_dense_wgrad_f32(const float* P, int64_t ldp, const float* G, int64_t ldg, int64_t M,
+                       int32_t F, int32_t d, float* dW, void* ws, size_t ws_bytes,
+                       mp_stream_t stream);
+
 /* ------------------------------------------------------------------ *
  * Identity-row update (K10): H[id[k], :] += U[k, :]                   *
  * replaces tf.tensor_scatter_nd_add (TfgIDLayer.py:107,165,330,515)   *

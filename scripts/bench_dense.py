@@ -24,8 +24,12 @@ for M in (1_000_000, 10_000_000):
         t_single = tm(lambda: ops._raw_dense_fused(P, W, None, None, b, True))
         t_dual_lib = tm(lambda: torch.relu(P @ W + Q @ Wi + b))
         t_dual = tm(lambda: ops._raw_dense_fused(P, W, Q, Wi, b, True))
+        g = torch.rand(M, d, device=dev) - 0.5
+        t_wg_lib = tm(lambda: P.t() @ g)
+        t_wg = tm(lambda: ops._raw_dense_wgrad(P, g))
+        del g
         fl = 2.0 * M * F * d
         print(f"M={M} F={F} d={d}: single lib {t_single_lib:7.2f} ms ({fl/t_single_lib/1e9:6.1f} TF) fused {t_single:7.2f} ms ({fl/t_single/1e9:6.1f} TF) | "
-              f"dual lib {t_dual_lib:7.2f} ms fused {t_dual:7.2f} ms ({2*fl/t_dual/1e9:6.1f} TF) | 256-col tile: single {t_single_tn2:7.2f} dual {t_dual_tn2:7.2f}", flush=True)
+              f"dual lib {t_dual_lib:7.2f} ms fused {t_dual:7.2f} ms ({2*fl/t_dual/1e9:6.1f} TF) | 256-col tile: single {t_single_tn2:7.2f} dual {t_dual_tn2:7.2f} | wgrad P^T g: lib {t_wg_lib:7.2f} ms engine {t_wg:7.2f} ms ({fl/t_wg/1e9:6.1f} TF)", flush=True)
         del P, Q
         torch.cuda.empty_cache()
