@@ -259,7 +259,7 @@ class SAGEIDConvLayer(nn.Module):
         aggr_out = ops.spmm(g, x, "mean")
         if self.concat:
             aggr_out = torch.cat([x, aggr_out], dim=-1)
-        out = torch.matmul(aggr_out, self.weight)
+        out = ops.dense_fused(aggr_out, self.weight)
         if id is not None:
             out = _id_branch(out, aggr_out, id, self.weight_id)
         if self.bias is not None:
@@ -668,8 +668,8 @@ class IDSAGE(_KerasLike):
         x, edge_index, id_index, edge_weight = _unpack(inputs, self.with_id)
         self._maybe_build(x)
         g = get_graph(holder, edge_index, x.size(0), dst_row=0, loops="none", edge_weight=edge_weight)
-        neighbor_msg = torch.matmul(ops.spmm(g, x, "mean"), self.neighbor_kernel)
-        h = torch.matmul(x, self.self_kernel)
+        neighbor_msg = ops.dense_fused(ops.spmm(g, x, "mean"), self.neighbor_kernel)
+        h = ops.dense_fused(x, self.self_kernel)
         if id_index is not None:
             h = _id_branch(h, x, id_index, self.id_kernel)
         h = torch.cat([h, neighbor_msg], dim=1) if self.concat else h + neighbor_msg
