@@ -329,6 +329,15 @@ def _raw_spmm_heads(g, a, V, heads):
     if heads == 1:   # one weight per entry: this is the hot aggregation kernel with val = a
         y, _ = _raw_spmm(g.with_values(a.reshape(-1).contiguous()), V, _lib.SUM)
         return y
+    if V.size(1) % heads == 0:
+        # H heads = H launches of the hot kernel on column slices (the ABI takes leading dimensions):
+        # head h aggregates V[:, h*dh:(h+1)*dh] with the entry values a[:, h]
+        dh = V.size(1) // heads
+        y = torch.empty((g.num_nodes, V.size(1)), dtype=torch.float32, device=V.device)
+        for h in range(heads):
+            _raw_spmm(g.with_values(a[:, h].contiguous()), V[:, h * dh:(h + 1) * dh], _lib.SUM,
+                      out=y[:, h * dh:(h + 1) * dh])
+        return y
     L = lib()
     y = torch.empty((g.num_nodes, V.size(1)), dtype=torch.float32, device=V.device)
     with torch.cuda.device(V.device):
