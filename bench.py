@@ -146,7 +146,7 @@ def main():
         achieved = balg / (launch_ms * 1e-3) / 1e9
         workload = f"gcn_norm_sum_d{d}_BA_n{n}_m{args.m}"
         res = {
-            "metric": "aggregated edges/sec, GCN-normalised sum aggregation d=256 on a 10M-node/100M-edge scale-free graph",
+            "metric": "aggregated edges/sec + achieved HBM GB/s, GCN d=256 on 100M-edge scale-free",
             "value": total_nnz * args.steps / dt,
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
