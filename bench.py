@@ -104,7 +104,17 @@ def main():
     # profiles/r01_placement.log); which region an allocation lands in is not under the
     # caller's control.  So the untimed set-up allocates a few candidate output buffers, times each
     # briefly, keeps the fastest and reports all of them.
-    cands = [torch.empty((n, d), dtype=torch.float32, device=dev) for _ in range(3)]
+    # Candidates are spaced ~36 GB apart (the size of the regions observed: 288 GB / 8) with throw-away
+    # allocations, so that they cannot all share X's region.
+    cands, spacers = [], []
+    for i in range(3):
+        cands.append(torch.empty((n, d), dtype=torch.float32, device=dev))
+        if i < 2:
+            try:
+                spacers.append(torch.empty(int(26e9), dtype=torch.uint8, device=dev))
+            except torch.OutOfMemoryError:
+                pass
+    del spacers
     cand_ms = []
     for c in cands:
         ops._raw_spmm(g, x, _lib.SUM, out=c)
