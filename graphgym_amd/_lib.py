@@ -41,6 +41,7 @@ PROTOTYPES = {
     "mp_mark_id_sources": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _p, _p]),
     "mp_spmm_plan_config": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mp_spmm_kernel_config": (C.c_int, [C.c_int, C.c_int]),
+    "mp_spmm_debug_xregions": (C.c_int, [C.c_int, _i64]),
     "mp_spmm_plan_bytes": (C.c_int, [_i64, _i64, _psz]),
     "mp_spmm_plan_build": (C.c_int, [_p, _i64, _i64, _p, _sz, _pi32, _p]),
     "mp_spmm_ws_bytes": (C.c_int, [_pi32, _i32, C.c_int, C.c_int, _psz]),

@@ -31,6 +31,7 @@ struct AggArgs {
   int32_t n_seg;
   int32_t hub_deg;
   const float* X; int64_t ldx;
+  int32_t xk; int64_t xstride;   // experiment: rows of X striped over xk memory regions (0/1 = plain row-major)
   float* Y; int64_t ldy;
   float* Q; int64_t ldq;
   const float* S; int64_t lds; float self_scale;
@@ -233,7 +234,12 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
         if constexpr (LDS_TILE) cj[j] = __builtin_amdgcn_readfirstlane(lds_col[wave * kWave + jb + j]);
         else cj[j] = bcast_i(cv, jb + j);
         const int c = BRANCH2 ? (cj[j] & 0x7fffffff) : cj[j];
-        load_vec<W>(xlane + (int64_t)c * a.ldx, v[j]);
+        if (a.xk > 1) {   // row c lives in region c % xk at slot c / xk (scalar arithmetic)
+          const int q = c / a.xk;
+          load_vec<W>(xlane + (int64_t)(c - q * a.xk) * a.xstride + (int64_t)q * a.ldx, v[j]);
+        } else {
+          load_vec<W>(xlane + (int64_t)c * a.ldx, v[j]);
+        }
       }
 #pragma unroll
       for (int j = 0; j < U; ++j) {
@@ -456,6 +462,8 @@ __global__ __launch_bounds__(kBlock) void plan_hub_kernel(const int32_t* __restr
 
 // ---- dispatch -------------------------------------------------------------
 
+static int g_xk = 0;                 // experiment knob (mp_spmm_debug_xregions)
+static int64_t g_xstride = 0;
 static int g_unroll = 8;   // rows in flight per wave (4, 8, 16)
 static int g_var = 1;      // VAR bits of agg_rows_kernel
 
@@ -571,6 +579,7 @@ static int agg_common(const int32_t* rowptr, const int32_t* col, const float* va
   a.hub_deg = counts[6];       // the config the plan was built under
   a.piece_edges = counts[7];
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.Q = Q; a.ldq = ldq;
+  a.xk = g_xk; a.xstride = g_xstride;
   a.S = S; a.lds = lds; a.self_scale = self_scale; a.bias = bias; a.act = act;
   a.col_scale = col_scale; a.l2norm = l2norm; a.l2_eps = l2_eps;
   a.argmax = argmax; a.d = d;
@@ -628,6 +637,16 @@ extern "C" {
 int mp_spmm_plan_config(int seg_cost, int row_cost, int hub_deg, int piece_edges) {
   if (seg_cost < 64 || row_cost < 0 || hub_deg < seg_cost || piece_edges < 64) return MP_ERR_INVALID_ARG;
   g_cfg = {seg_cost, row_cost, hub_deg, piece_edges};
+  return MP_OK;
+}
+
+// EXPERIMENT (layout study): the main aggregation kernel reads row c of X at
+// X + (c % k) * stride_floats + (c / k) * ldx, i.e. rows striped over k memory regions.  k <= 1 restores
+// the plain row-major addressing.  Hub rows keep plain addressing, so only use it for timing studies.
+int mp_spmm_debug_xregions(int k, int64_t stride_floats) {
+  if (k < 0 || k > 64 || stride_floats < 0) return MP_ERR_INVALID_ARG;
+  g_xk = k;
+  g_xstride = stride_floats;
   return MP_OK;
 }
 

@@ -151,6 +151,9 @@ int mp_spmm_plan_config(int seg_cost, int row_cost, int hub_deg, int piece_edges
  * stores of Y, 2 = non-temporal index loads, 4 = prefetch of the next index tile, 8 = index tile
  * staged through LDS instead of v_readlane (kept for the record: DESIGN.md §7).  Default 8, 1. */
 int mp_spmm_kernel_config(int rows_in_flight, int variant_bits);
+/* layout experiment only (timing studies; results are wrong for hub rows): read row c of X at
+ * X + (c % k) * stride_floats + (c / k) * ldx.  k <= 1 = off (default). */
+int mp_spmm_debug_xregions(int k, int64_t stride_floats);
 int mp_spmm_plan_bytes(int64_t N, int64_t nnz, size_t* bytes_host);
 /* counts_host[8] <- {n_seg, n_hub, n_piece, cap_hub, cap_piece, seg_cost, hub_deg,
  * piece_edges}; SYNCHRONISES `stream` (once per graph) */
