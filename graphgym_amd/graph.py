@@ -250,8 +250,19 @@ class CSRGraph:
         return g
 
     def mark_ids(self, id_index):
-        """col with the sign bit set on entries whose source is an identity node"""
+        """col with the sign bit set on entries whose source is an identity node; cached per index tensor
+        (the mark depends only on the pattern, so graphs sharing a pattern share it)"""
         _require_hip(id_index, "id_index")
+        owner = getattr(self, "_pattern_of", None) or self
+        stamp = (id_index.data_ptr(), id_index.numel(), id_index._version)
+        cache = owner.__dict__.setdefault("_id_marks", {})
+        if stamp not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[stamp] = self._mark_ids(id_index)
+        return cache[stamp]
+
+    def _mark_ids(self, id_index):
         L = lib()
         ids = id_index.to(torch.int64).contiguous()
         flag = torch.empty(max(self.num_nodes, 1), dtype=torch.uint8, device=self.device)
