@@ -33,6 +33,14 @@ with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w.writeheader()
     w.writerows(rows)
 
+timed = None
+for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv")):
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f))
+         if "agg_rows_kernel" in r["Kernel_Name"]]
+    if len(d) >= 10:
+        timed = {"launches_in_trace": len(d), "last_10_launches_avg_ns": sum(d[-10:]) / 10, "min_ns": min(d),
+                 "note": "the last 10 launches are bench.py's timed region (--steps 10); earlier ones are plan warm-up and "
+                         "the three candidate output buffers (one or two of them in the slow placement band)"}
 pmc = {}
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for f in glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv")):
@@ -57,6 +65,7 @@ rec = {"workload": workload, "kernel": main, "fetch_bytes_corrected": fetch, "wr
        "hbm_bytes_per_launch": fetch + write,
        "note": "FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md §HBM), KiB units, separate --pmc passes; "
                "counters sit on the L2's fabric side, so Infinity-Cache hits are included",
+       "kernel_trace_timed_region": timed,
        "per_kernel": summary}
 json.dump(rec, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 json.dump({"workload": workload, "hbm_bytes_per_launch": fetch + write, "source": f"profiles/{tag}_pmc.json"},
