@@ -521,3 +521,48 @@ def test_dense_fused_mfma_kernel(dev, M, F, d, dual):
         close(a.grad, rr.grad, 2e-4)
     # the raw kernel really ran for these shapes (no library fallback)
     assert ops._raw_dense_fused(P.to(dev), W.to(dev), None, None, None, False) is not None
+
+
+def test_c_abi_error_codes_on_device(dev):
+    """status codes, not exceptions or faults: too-small workspace, bad enums, bad leading dimensions"""
+    import ctypes as C
+    import graphgym_amd as ga
+    from graphgym_amd import _lib
+    from graphgym_amd._lib import ptr
+    from graphgym_amd.graph import _stream
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    N, d = 64, 32
+    ei = torch.stack([torch.randint(0, N, (5000,), generator=g), torch.zeros(5000, dtype=torch.int64)])  # one hub row
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N)
+    plan, counts = G.plan()
+    assert counts[1] == 1 and counts[2] > 0                      # the hub path is live, so a workspace is required
+    x = torch.randn(N, d, device=dev)
+    y = torch.empty(N, d, device=dev)
+    args = lambda ws, nb, reduce=0, ldx=d, act=0: L.mp_spmm_csr_f32(
+        ptr(G.rowptr), ptr(G.col), None, N, ptr(plan), counts, ptr(x), ldx, ptr(y), d, d, reduce, None, 0, 0.0,
+        None, act, None, ws, nb, _stream())
+    nb = C.c_size_t(0)
+    assert L.mp_spmm_ws_bytes(counts, d, 0, 0, C.byref(nb)) == 0 and nb.value > 0
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    assert args(ptr(ws), nb.value) == 0
+    assert args(None, 0) == 3                                    # MP_ERR_WORKSPACE
+    assert args(ptr(ws), nb.value - 1) == 3
+    assert args(ptr(ws), nb.value, reduce=7) == 1                # MP_ERR_INVALID_ARG
+    assert args(ptr(ws), nb.value, ldx=d - 1) == 1
+    assert args(ptr(ws), nb.value, act=9) == 1
+    with pytest.raises(_lib.EngineError, match="workspace"):
+        _lib.check(args(None, 0), "mp_spmm_csr_f32")
+    torch.cuda.synchronize()
+    # fused-epilogue L2 normalisation refuses rows wider than one wave instead of computing a partial norm
+    xw = torch.randn(N, 512, device=dev)
+    yw = torch.empty(N, 512, device=dev)
+    nbw = C.c_size_t(0)
+    L.mp_spmm_ws_bytes(counts, 512, 0, 0, C.byref(nbw))
+    wsw = torch.empty(nbw.value, dtype=torch.uint8, device=dev)
+    st = L.mp_spmm_csr_epilogue_f32(ptr(G.rowptr), ptr(G.col), None, N, ptr(plan), counts, ptr(xw), 512, ptr(yw), 512,
+                                    512, 0, None, 0, 0.0, None, None, 0, 1, 1e-12, ptr(wsw), nbw.value, _stream())
+    assert st == 2                                               # MP_ERR_UNSUPPORTED
+    # dense kernel: unsupported widths are reported, not mis-computed
+    P = torch.randn(10, 12, device=dev); W = torch.randn(12, 8, device=dev); out = torch.empty(10, 8, device=dev)
+    assert L.mp_dense_fused_f32(ptr(P), 12, ptr(W), None, 0, None, None, 0, ptr(out), 8, 10, 12, 8, _stream()) == 2
