@@ -151,6 +151,20 @@ def main():
     per_step = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
     launch_ms = sum(per_step) / args.steps
 
+    # measured copy bandwidth on this box, same two buffers (read X, write Y): the practical HBM ceiling
+    from graphgym_amd._lib import lib as _mplib, ptr as _ptr, check as _check
+    from graphgym_amd.graph import _stream as _mpstream
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ysave = y[:1].clone()
+    _check(_mplib().mp_copy_probe_f32(_ptr(x), _ptr(y), x.numel(), _mpstream()))
+    c0.record()
+    for _ in range(3):
+        _check(_mplib().mp_copy_probe_f32(_ptr(x), _ptr(y), x.numel(), _mpstream()))
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 2 * x.numel() * 4 / (c0.elapsed_time(c1) / 3 * 1e-3) / 1e9
+    del ysave
+
     if rank == 0:
         balg = algorithmic_bytes(n, g.nnz, d, g.val is not None)
         achieved = balg / (launch_ms * 1e-3) / 1e9
@@ -174,6 +188,7 @@ def main():
             "hbm_gbps_algorithmic": achieved,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(workload),
+                         "copy_gbps_measured": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
                          "algorithmic_bytes_per_launch": balg, "launch_ms": launch_ms,
                          "launch_ms_min_median_max": [per_step[0], per_step[len(per_step) // 2], per_step[-1]],
                          "kernel": "mp::agg_rows_kernel<4,SUM,weighted> (+ hub pieces/finalize, same launch group)"},

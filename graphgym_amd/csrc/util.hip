@@ -10,9 +10,29 @@ void set_hip_error(hipError_t e, const char* what) {
 }
 }  // namespace mp
 
+namespace mp {
+typedef float cp_f32x4 __attribute__((ext_vector_type(4)));
+// plain streaming copy, 16 B per lane: the yardstick the aggregation's HBM rate is quoted against
+__global__ __launch_bounds__(kBlock) void copy_probe_kernel(const cp_f32x4* __restrict__ src,
+                                                            cp_f32x4* __restrict__ dst, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    __builtin_nontemporal_store(src[i], dst + i);
+}
+}  // namespace mp
+
 extern "C" {
 
 int mp_version(void) { return 100; }
+
+int mp_copy_probe_f32(const float* src, float* dst, int64_t n, mp_stream_t stream) {
+  if (n < 0 || (n > 0 && (!src || !dst)) || n % 4 || ((uintptr_t)src % 16) || ((uintptr_t)dst % 16))
+    return MP_ERR_INVALID_ARG;
+  if (n == 0) return MP_OK;
+  hipLaunchKernelGGL(mp::copy_probe_kernel, dim3(mp::kNumCU * 8), dim3(mp::kBlock), 0, mp::as_stream(stream),
+                     reinterpret_cast<const mp::cp_f32x4*>(src), reinterpret_cast<mp::cp_f32x4*>(dst), n / 4);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
 
 const char* mp_status_str(int status) {
   switch (status) {
