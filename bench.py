@@ -155,7 +155,6 @@ def main():
     from graphgym_amd._lib import lib as _mplib, ptr as _ptr, check as _check
     from graphgym_amd.graph import _stream as _mpstream
     c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ysave = y[:1].clone()
     _check(_mplib().mp_copy_probe_f32(_ptr(x), _ptr(y), x.numel(), _mpstream()))
     c0.record()
     for _ in range(3):
@@ -163,7 +162,6 @@ def main():
     c1.record()
     torch.cuda.synchronize()
     copy_gbps = 2 * x.numel() * 4 / (c0.elapsed_time(c1) / 3 * 1e-3) / 1e9
-    del ysave
 
     if rank == 0:
         balg = algorithmic_bytes(n, g.nnz, d, g.val is not None)
