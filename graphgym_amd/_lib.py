@@ -29,6 +29,7 @@ _pi32 = C.POINTER(C.c_int32)
 PROTOTYPES = {
     "mp_version": (C.c_int, []),
     "mp_copy_probe_f32": (C.c_int, [_p, _p, _i64, _p]),
+    "mp_read_probe_f32": (C.c_int, [_p, _i64, _p, _p]),
     "mp_status_str": (C.c_char_p, [C.c_int]),
     "mp_last_hip_error": (C.c_char_p, []),
     "mp_csr_from_coo_ws_bytes": (C.c_int, [_i64, _i64, _psz]),

@@ -18,11 +18,27 @@ __global__ __launch_bounds__(kBlock) void copy_probe_kernel(const cp_f32x4* __re
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
     __builtin_nontemporal_store(src[i], dst + i);
 }
+// read-only stream: every lane sums its 16-byte loads; one float per lane is written so nothing is elided
+__global__ __launch_bounds__(kBlock) void read_probe_kernel(const cp_f32x4* __restrict__ src, int64_t n4,
+                                                            float* __restrict__ sink) {
+  cp_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    acc += src[i];
+  sink[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+}
 }  // namespace mp
 
 extern "C" {
 
 int mp_version(void) { return 100; }
+
+int mp_read_probe_f32(const float* src, int64_t n, float* sink, mp_stream_t stream) {
+  if (n < 0 || !sink || (n > 0 && !src) || n % 4 || ((uintptr_t)src % 16)) return MP_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(mp::read_probe_kernel, dim3(mp::kNumCU * 8), dim3(mp::kBlock), 0, mp::as_stream(stream),
+                     reinterpret_cast<const mp::cp_f32x4*>(src), n / 4, sink);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
 
 int mp_copy_probe_f32(const float* src, float* dst, int64_t n, mp_stream_t stream) {
   if (n < 0 || (n > 0 && (!src || !dst)) || n % 4 || ((uintptr_t)src % 16) || ((uintptr_t)dst % 16))

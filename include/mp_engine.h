@@ -67,6 +67,8 @@ int mp_version(void);
 /* streaming device copy of n floats (n % 4 == 0, 16-byte aligned), 16 B per lane: the measured-bandwidth
  * yardstick bench.py reports beside the nominal HBM peak */
 int mp_copy_probe_f32(const float* src, float* dst, int64_t n, mp_stream_t stream);
+/* read-only stream of n floats; sink must hold 256 * 8 * 256 floats (one per launched lane) */
+int mp_read_probe_f32(const float* src, int64_t n, float* sink, mp_stream_t stream);
 const char* mp_status_str(int status);
 /* text of the last failing HIP call on this thread ("" if none) */
 const char* mp_last_hip_error(void);
