@@ -113,3 +113,15 @@ def test_gradient_all_reduce_gloo_world2(tmp_path):
         assert torch.allclose(ga, (la + lb) / 2, atol=1e-6)
         assert torch.equal(ga, gb)                                   # ranks end with identical gradients
     assert a["tmax"] == 2.0 and a["tsum"] == 4.0
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """no CPU path: on a box without a HIP device bench.py exits with a message instead of a fallback"""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
