@@ -90,7 +90,7 @@ def test_idgcn_model_step_matches_oracle(dev):
     kern = [P[k] for k in P if k.endswith("kernel") or k.endswith("kernel_id") or k.endswith(".weight")]
     ref = ce + 5e-4 * sum((p * p).sum() / 2 for p in kern)
     ref.backward()
-    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
     for k, p in model.named_parameters():
         g, gr = p.grad.cpu(), P[k].grad
         assert float((g - gr).abs().max()) <= 1e-4 * max(1.0, float(gr.abs().max())), k
