@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--m", type=int, default=5)
     ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--graph", choices=["ba", "powerlaw_cluster"], default="ba",
+                    help="ba = Barabasi-Albert (default); powerlaw_cluster = Holme-Kim with triangle probability 0.3")
+    ap.add_argument("--permute", action="store_true", help="relabel nodes by a random permutation (seed 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -93,7 +96,9 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     n, d = args.nodes, args.d
-    ei = graphgen.ba_edge_index(n, args.m, seed=12345 + rank, device=dev)
+    ei = graphgen.ba_edge_index(n, args.m, seed=12345 + rank, device=dev,
+                                triangle_p=0.3 if args.graph == "powerlaw_cluster" else None,
+                                permute_seed=1 if args.permute else None)
     g = ga.CSRGraph.from_edge_index(ei, n, add_self_loops=True).gcn_norm("row")
     del ei
     g.plan()
@@ -174,7 +179,8 @@ def main():
     if rank == 0:
         balg = algorithmic_bytes(n, g.nnz, d, g.val is not None)
         achieved = balg / (launch_ms * 1e-3) / 1e9
-        workload = f"gcn_norm_sum_d{d}_BA_n{n}_m{args.m}"
+        gname = "BA" if args.graph == "ba" else "HK0.3"
+        workload = f"gcn_norm_sum_d{d}_{gname}_n{n}_m{args.m}" + ("_perm" if args.permute else "")
         res = {
             "metric": "aggregated edges/sec + achieved HBM GB/s, GCN d=256 on 100M-edge scale-free",
             "value": total_nnz * args.steps / dt,
@@ -185,7 +191,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "nodes_per_gpu": n, "stored_entries_per_gpu": g.nnz,
                        "feature_dim": d, "reduce": "sum", "edge_weights": "D^-1/2 (A+I) D^-1/2",
-                       "graph": f"Barabasi-Albert BA({n},{args.m}) seed 12345+rank, symmetrised, deduplicated, self loops added",
+                       "graph": (f"Barabasi-Albert BA({n},{args.m})" if args.graph == "ba" else
+                                 f"Holme-Kim powerlaw_cluster({n},{args.m},0.3)") +
+                                " seed 12345+rank, symmetrised, deduplicated, self loops added" +
+                                (", nodes randomly relabelled" if args.permute else ""),
                        "index_dtype": "int32",
                        "output_placement": {"candidate_buffers_ms": cand_ms,
                                             "note": "fastest of 3 candidate Y buffers chosen in untimed set-up; "

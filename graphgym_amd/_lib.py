@@ -71,6 +71,7 @@ PROTOTYPES = {
     "mp_ego_expand_count": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _sz, _p, _p]),
     "mp_ego_expand_emit": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _sz, _p, _p, _p, _p, _p]),
     "mp_gen_ba_edges_host": (C.c_int, [_i64, _i32, C.c_uint64, _p, _p, _p]),
+    "mp_gen_powerlaw_cluster_edges_host": (C.c_int, [_i64, _i32, C.c_double, C.c_uint64, _p, _p, _p]),
 }
 
 _lib = None

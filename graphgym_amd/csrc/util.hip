@@ -103,4 +103,64 @@ int mp_gen_ba_edges_host(int64_t n, int32_t m, uint64_t seed, int64_t* u_host, i
   return MP_OK;
 }
 
+// Holme-Kim "powerlaw cluster" growth (networkx.powerlaw_cluster_graph, the generator behind the reference's
+// datasets/scalefree.pkl, datasets/syn_graph.py:42): each new node makes m links; after a preferential
+// attachment step to target t, with probability p the next link closes a triangle by going to a uniformly
+// chosen neighbour of t that the new node is not linked to yet, else it is another preferential step.
+// Adjacency lists are kept on the host (about 0.7 GB at n = 10^7, m = 5).  Links of one node are distinct.
+int mp_gen_powerlaw_cluster_edges_host(int64_t n, int32_t m, double p, uint64_t seed, int64_t* u_host,
+                                       int64_t* v_host, int64_t* n_edges_host) {
+  if (n <= m || m < 1 || p < 0.0 || p > 1.0 || !u_host || !v_host || !n_edges_host) return MP_ERR_INVALID_ARG;
+  if (n >= INT32_MAX) return MP_ERR_UNSUPPORTED;
+  std::vector<std::vector<int32_t>> adj((size_t)n);
+  std::vector<int32_t> ends;                 // every edge endpoint once: degree-proportional sampling
+  ends.reserve((size_t)(2 * (int64_t)m * n + m));
+  for (int32_t i = 0; i < m; ++i) ends.push_back(i);
+  uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ull;
+  auto next = [&]() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  auto below = [&](size_t k) { return (size_t)(((unsigned __int128)next() * k) >> 64); };
+  auto unit = [&]() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); };
+  int64_t k = 0;
+  std::vector<int32_t> mine;
+  mine.reserve((size_t)m);
+  for (int64_t t = m; t < n; ++t) {
+    mine.clear();
+    auto linked = [&](int32_t x) { for (int32_t y : mine) if (y == x) return true; return false; };
+    const size_t pool = ends.size();
+    int32_t last = -1;
+    int guard = 0;
+    while ((int32_t)mine.size() < m && guard < 64 * m) {
+      ++guard;
+      int32_t tgt = -1;
+      if (last >= 0 && unit() < p && !adj[(size_t)last].empty()) {
+        const int32_t cand = adj[(size_t)last][below(adj[(size_t)last].size())];   // triad formation
+        if (cand != (int32_t)t && !linked(cand)) tgt = cand;
+      }
+      if (tgt < 0) {
+        const int32_t cand = ends[below(pool)];                                     // preferential attachment
+        if (linked(cand)) continue;
+        tgt = cand;
+      }
+      mine.push_back(tgt);
+      last = tgt;
+    }
+    for (int32_t tgt : mine) {
+      u_host[k] = t;
+      v_host[k] = tgt;
+      ++k;
+      adj[(size_t)t].push_back(tgt);
+      adj[(size_t)tgt].push_back((int32_t)t);
+      ends.push_back((int32_t)t);
+      ends.push_back(tgt);
+    }
+  }
+  *n_edges_host = k;
+  return MP_OK;
+}
+
 }  // extern "C"

@@ -334,6 +334,11 @@ int mp_ego_expand_emit(const int32_t* rowptr, const int32_t* col, int64_t N,
 int mp_gen_ba_edges_host(int64_t n, int32_t m, uint64_t seed,
                          int64_t* u_host, int64_t* v_host, int64_t* n_edges_host);
 
+/* Holme-Kim powerlaw-cluster growth (networkx.powerlaw_cluster_graph(n, m, p), datasets/syn_graph.py:42):
+ * preferential attachment with probability-p triangle closing.  At most m*(n-m) pairs (u > v). */
+int mp_gen_powerlaw_cluster_edges_host(int64_t n, int32_t m, double p, uint64_t seed,
+                                       int64_t* u_host, int64_t* v_host, int64_t* n_edges_host);
+
 #ifdef __cplusplus
 }
 #endif

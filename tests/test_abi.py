@@ -86,3 +86,21 @@ def test_ops_refuse_cpu_tensors():
     ei = torch.tensor([[0, 1], [1, 0]])
     with pytest.raises(ga.EngineError):
         ga.CSRGraph.from_edge_index(ei, 2)
+
+
+def test_powerlaw_cluster_generator_host():
+    """Holme-Kim growth: same degree budget as BA, but triangles (clustering) like networkx's generator"""
+    import networkx as nx
+    from graphgym_amd import graphgen
+    u, v = graphgen.powerlaw_cluster_undirected_pairs(4000, 4, 0.5, seed=2)
+    assert (u > v).all() and v.min() >= 0 and u.max() == 3999 and u.size <= 4 * (4000 - 4)
+    pairs = set(zip(u.tolist(), v.tolist()))
+    assert len(pairs) == u.size                                          # links of one node are distinct
+    G = nx.Graph(); G.add_edges_from(pairs)
+    ref = nx.powerlaw_cluster_graph(4000, 4, 0.5, seed=2)
+    ba_u, ba_v = graphgen.ba_undirected_pairs(4000, 4, seed=2)
+    B = nx.Graph(); B.add_edges_from(zip(ba_u.tolist(), ba_v.tolist()))
+    c, cref, cba = nx.average_clustering(G), nx.average_clustering(ref), nx.average_clustering(B)
+    assert cba < 0.05 < c and abs(c - cref) < 0.5 * cref                 # triangle closing is really there
+    u2, v2 = graphgen.powerlaw_cluster_undirected_pairs(4000, 4, 0.5, seed=2)
+    assert (u == u2).all() and (v == v2).all()
