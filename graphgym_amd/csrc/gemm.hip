@@ -24,7 +24,9 @@ constexpr int BM = 128, BK = 16, APAD = 17;
 // TN = 32-column MFMA tiles per wave along N: block tile 128 x (64 * TN).  TN = 2 (128 columns, 3 waves per
 // SIMD) is the default; TN = 4 (256 columns: every A row read once at d <= 256) needs 297 registers, runs
 // one wave per SIMD and measured 25 % slower — kept behind mp_dense_config(4) for the record.
-template <bool DUAL, int TN>
+// VEC = operands allow 16-byte loads (F % 8 == 0, d % 4 == 0, aligned rows); otherwise the loaders fall back to
+// guarded scalar loads (any F, d, leading dimension: e.g. Cora's F = 1433) and everything else is unchanged.
+template <bool DUAL, int TN, bool VEC>
 __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(const float* __restrict__ P, int64_t ldp,
                                                              const float* __restrict__ W,
                                                              const float* __restrict__ Q, int64_t ldq,
@@ -57,21 +59,40 @@ __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(co
 
   f32x4 ra[2], rb[NB4];
   auto fetch = [&](int kt) {
-    // A: 8 consecutive k of one row, from P or (past F) from Q; F % 8 == 0 keeps a fetch inside one operand
-    const int k = kt + a_k;
-    const bool second = DUAL && k >= F;
-    const float* src = second ? Q + g_row * ldq + (k - F) : P + g_row * ldp + k;
-    const bool ok = row_ok && k < KT;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    ra[0] = ok ? *reinterpret_cast<const f32x4*>(src) : z;
-    ra[1] = ok ? *reinterpret_cast<const f32x4*>(src + 4) : z;
-    // B: 8 consecutive n of one k row of W or W_id
+    const int k = kt + a_k;
     const int kb = kt + b_k;
-    const bool second_b = DUAL && kb >= F;
-    const float* wsrc = (second_b ? Wid + (int64_t)(kb - F) * d : W + (int64_t)kb * d) + n0 + b_n;
+    if constexpr (VEC) {
+      // A: 8 consecutive k of one row, from P or (past F) from Q; F % 8 == 0 keeps a fetch inside one operand
+      const bool second = DUAL && k >= F;
+      const float* src = second ? Q + g_row * ldq + (k - F) : P + g_row * ldp + k;
+      const bool ok = row_ok && k < KT;
+      ra[0] = ok ? *reinterpret_cast<const f32x4*>(src) : z;
+      ra[1] = ok ? *reinterpret_cast<const f32x4*>(src + 4) : z;
+      // B: consecutive n of one k row of W or W_id
+      const bool second_b = DUAL && kb >= F;
+      const float* wsrc = (second_b ? Wid + (int64_t)(kb - F) * d : W + (int64_t)kb * d) + n0 + b_n;
 #pragma unroll
-    for (int q = 0; q < NB4; ++q)
-      rb[q] = (kb < KT && n0 + b_n + 4 * q < d) ? *reinterpret_cast<const f32x4*>(wsrc + 4 * q) : z;
+      for (int q = 0; q < NB4; ++q)
+        rb[q] = (kb < KT && n0 + b_n + 4 * q < d) ? *reinterpret_cast<const f32x4*>(wsrc + 4 * q) : z;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ki = k + i;
+        float v = 0.f;
+        if (row_ok && ki < KT) v = (DUAL && ki >= F) ? Q[g_row * ldq + (ki - F)] : P[g_row * ldp + ki];
+        ra[i >> 2][i & 3] = v;
+      }
+      const bool second_b = DUAL && kb >= F;
+      const float* wrow = second_b ? Wid + (int64_t)(kb - F) * d : W + (int64_t)kb * d;
+#pragma unroll
+      for (int q = 0; q < NB4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int nn = n0 + b_n + 4 * q + i;
+          rb[q][i] = (kb < KT && nn < d) ? wrow[nn] : 0.f;
+        }
+    }
   };
   auto stash = [&](int buf) {
 #pragma unroll
@@ -142,7 +163,7 @@ __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(co
 // 32 consecutive words.  Split-K over nodes: a block owns `chunk` rows and one 128 x 128 output tile and
 // writes its partial to a slab; a second kernel adds the slabs in chunk order (bitwise reproducible, unlike
 // float atomics).
-template <int DUMMY>
+template <bool VEC>
 __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __restrict__ P, int64_t ldp,
                                                                 const float* __restrict__ G, int64_t ldg,
                                                                 int64_t M, int32_t F, int32_t d, int64_t chunk,
@@ -168,10 +189,18 @@ __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __r
     const bool ok = m < me;
     const float* ps = P + m * ldp + f0 + l_col;
     const float* gs = G + m * ldg + d0 + l_col;
-    rp[0] = (ok && f0 + l_col < F) ? *reinterpret_cast<const f32x4*>(ps) : z;
-    rp[1] = (ok && f0 + l_col + 4 < F) ? *reinterpret_cast<const f32x4*>(ps + 4) : z;
-    rg[0] = (ok && d0 + l_col < d) ? *reinterpret_cast<const f32x4*>(gs) : z;
-    rg[1] = (ok && d0 + l_col + 4 < d) ? *reinterpret_cast<const f32x4*>(gs + 4) : z;
+    if constexpr (VEC) {
+      rp[0] = (ok && f0 + l_col < F) ? *reinterpret_cast<const f32x4*>(ps) : z;
+      rp[1] = (ok && f0 + l_col + 4 < F) ? *reinterpret_cast<const f32x4*>(ps + 4) : z;
+      rg[0] = (ok && d0 + l_col < d) ? *reinterpret_cast<const f32x4*>(gs) : z;
+      rg[1] = (ok && d0 + l_col + 4 < d) ? *reinterpret_cast<const f32x4*>(gs + 4) : z;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        rp[i >> 2][i & 3] = (ok && f0 + l_col + i < F) ? ps[i] : 0.f;
+        rg[i >> 2][i & 3] = (ok && d0 + l_col + i < d) ? gs[i] : 0.f;
+      }
+    }
   };
   auto stash = [&](int buf) {
     *reinterpret_cast<f32x4*>(&Ps[buf][l_row][l_col]) = rp[0];
@@ -264,20 +293,20 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W, const float*
   if ((Q == nullptr) != (Wid == nullptr) || (Q && ldq < F)) return MP_ERR_INVALID_ARG;
   if (act != MP_ACT_NONE && act != MP_ACT_RELU) return MP_ERR_INVALID_ARG;
   if (M == 0) return MP_OK;
-  // 16-byte vector loads: operand widths in multiples of 8 (F) / 4 (d) and aligned bases
-  if (F % 8 || d % 4 || ldp % 4 || (Q && ldq % 4)) return MP_ERR_UNSUPPORTED;
-  if (!al16(P) || !al16(W) || !al16(Q) || !al16(Wid)) return MP_ERR_ALIGNMENT;
-  const int tn = (d > 128 && g_dense_tn == 4) ? 4 : 2;   // the 256-column tile fits one wave per SIMD only: slower
+  // 16-byte vector loads need operand widths in multiples of 8 (F) / 4 (d) and aligned rows; else scalar loaders
+  const bool vec = !(F % 8 || d % 4 || ldp % 4 || (Q && ldq % 4)) && al16(P) && al16(W) && al16(Q) && al16(Wid);
+  const int tn = (vec && d > 128 && g_dense_tn == 4) ? 4 : 2;   // the 256-column tile fits one wave per SIMD only: slower
   const int bn = 64 * tn;
   const int64_t nblocks = ceil_div(d, bn) * ceil_div(M, BM);
   if (nblocks >= INT32_MAX) return MP_ERR_UNSUPPORTED;
   dim3 grid((unsigned)nblocks);
   hipStream_t st = as_stream(stream);
-#define MP_DENSE(DUALV, TNV)                                                                             \
-  hipLaunchKernelGGL((dense_fused_kernel<DUALV, TNV>), grid, dim3(kBlock), 0, st, P, ldp, W, Q, ldq, Wid, bias, \
-                     act, out, ldo, M, F, d)
-  if (Q) { if (tn == 4) MP_DENSE(true, 4); else MP_DENSE(true, 2); }
-  else { if (tn == 4) MP_DENSE(false, 4); else MP_DENSE(false, 2); }
+#define MP_DENSE(DUALV, TNV, VECV)                                                                        \
+  hipLaunchKernelGGL((dense_fused_kernel<DUALV, TNV, VECV>), grid, dim3(kBlock), 0, st, P, ldp, W, Q, ldq, Wid, \
+                     bias, act, out, ldo, M, F, d)
+  if (!vec) { if (Q) MP_DENSE(true, 2, false); else MP_DENSE(false, 2, false); }
+  else if (Q) { if (tn == 4) MP_DENSE(true, 4, true); else MP_DENSE(true, 2, true); }
+  else { if (tn == 4) MP_DENSE(false, 4, true); else MP_DENSE(false, 2, true); }
 #undef MP_DENSE
   MP_LAUNCH_CHECK();
   return MP_OK;
@@ -297,16 +326,19 @@ int mp_dense_wgrad_f32(const float* P, int64_t ldp, const float* G, int64_t ldg,
     MP_HIP(hipMemsetAsync(dW, 0, (size_t)F * d * 4, st));
     return MP_OK;
   }
-  if (F % 4 || d % 4 || ldp % 4 || ldg % 4) return MP_ERR_UNSUPPORTED;
-  if (!al16(P) || !al16(G)) return MP_ERR_ALIGNMENT;
+  const bool vec = !(F % 4 || d % 4 || ldp % 4 || ldg % 4) && al16(P) && al16(G);
   const int64_t chunk = wgrad_chunk(M);
   const int64_t n_chunk = ceil_div(M, chunk);
   const size_t need = (size_t)n_chunk * F * d * 4;
   if (!ws || ws_bytes < need) return MP_ERR_WORKSPACE;
   const int64_t tiles = ceil_div(F, 128) * ceil_div(d, 128);
   if (tiles * n_chunk >= INT32_MAX) return MP_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((dense_wgrad_kernel<0>), dim3((unsigned)(tiles * n_chunk)), dim3(kBlock), 0, st, P, ldp, G, ldg,
-                     M, F, d, chunk, (float*)ws);
+  if (vec)
+    hipLaunchKernelGGL((dense_wgrad_kernel<true>), dim3((unsigned)(tiles * n_chunk)), dim3(kBlock), 0, st, P, ldp, G,
+                       ldg, M, F, d, chunk, (float*)ws);
+  else
+    hipLaunchKernelGGL((dense_wgrad_kernel<false>), dim3((unsigned)(tiles * n_chunk)), dim3(kBlock), 0, st, P, ldp, G,
+                       ldg, M, F, d, chunk, (float*)ws);
   MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)F * d)), dim3(kBlock), 0, st, (const float*)ws,
                      n_chunk, (int64_t)F * d, dW);

@@ -236,8 +236,8 @@ int mp_spmm_max_bwd_f32(const int32_t* col, const float* val, const int32_t* arg
  * product.  fp32 on the matrix cores (v_mfma_f32_32x32x2_f32).          *
  * Replaces x @ kernel, x_id @ kernel_id, scatter-add, + bias, activation *
  * of gcn_id in its post-aggregation form (TfgIDLayer.py:510-523;        *
- * idconv.py:152-184).  Needs F % 8 == 0, d % 4 == 0, 16-byte aligned    *
- * operands (MP_ERR_UNSUPPORTED / MP_ERR_ALIGNMENT otherwise).           *
+ * idconv.py:152-184).  Any F, d and leading dimensions; 16-byte loads  *
+ * when F % 8 == 0, d % 4 == 0 and rows are 16-byte aligned.             *
  * ------------------------------------------------------------------ */
 /* tuning knob: 0 / 2 = 128-column block tile (default), 4 = 256-column tile when d > 128 */
 int mp_dense_config(int force_tn);
@@ -248,7 +248,7 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W,
 
 /* weight gradient of the transform: dW [F, d] = P^T @ G with P [M, F], G [M, d] (backward of K11 under
  * loss.backward(), graphgym/train.py:24).  Split over the node axis into slabs in `ws`
- * (mp_dense_wgrad_ws_bytes), summed in a fixed order: bitwise reproducible.  F % 4 == 0, d % 4 == 0. */
+ * (mp_dense_wgrad_ws_bytes), summed in a fixed order: bitwise reproducible.  Any F, d. */
 int mp_dense_wgrad_ws_bytes(int64_t M, int32_t F, int32_t d, size_t* bytes_host);
 int mp_dense_wgrad_f32(const float* P, int64_t ldp, const float* G, int64_t ldg, int64_t M,
                        int32_t F, int32_t d, float* dW, void* ws, size_t ws_bytes,

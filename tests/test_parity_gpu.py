@@ -491,7 +491,8 @@ def test_randomised_graphs_under_a_tiny_plan(dev):
 
 
 @pytest.mark.parametrize("M,F,d", [(1, 8, 4), (127, 16, 64), (128, 64, 128), (129, 72, 100), (1000, 256, 256),
-                                   (777, 264, 132), (300, 128, 512), (4100, 8, 260)])
+                                   (777, 264, 132), (300, 128, 512), (4100, 8, 260),
+                                   (500, 1433, 128), (333, 1, 7), (64, 13, 33), (2000, 30, 1)])   # scalar-loader shapes
 @pytest.mark.parametrize("dual", [False, True])
 def test_dense_fused_mfma_kernel(dev, M, F, d, dual):
     """act(P @ W [+ Q @ W_id] + bias) on the f32 MFMA kernel vs float64 on the host (forward), and its
@@ -563,6 +564,7 @@ def test_c_abi_error_codes_on_device(dev):
     st = L.mp_spmm_csr_epilogue_f32(ptr(G.rowptr), ptr(G.col), None, N, ptr(plan), counts, ptr(xw), 512, ptr(yw), 512,
                                     512, 0, None, 0, 0.0, None, None, 0, 1, 1e-12, ptr(wsw), nbw.value, _stream())
     assert st == 2                                               # MP_ERR_UNSUPPORTED
-    # dense kernel: unsupported widths are reported, not mis-computed
+    # dense kernel: inconsistent operands are rejected
     P = torch.randn(10, 12, device=dev); W = torch.randn(12, 8, device=dev); out = torch.empty(10, 8, device=dev)
-    assert L.mp_dense_fused_f32(ptr(P), 12, ptr(W), None, 0, None, None, 0, ptr(out), 8, 10, 12, 8, _stream()) == 2
+    assert L.mp_dense_fused_f32(ptr(P), 12, ptr(W), ptr(P), 12, None, None, 0, ptr(out), 8, 10, 12, 8, _stream()) == 1
+    assert L.mp_dense_fused_f32(ptr(P), 11, ptr(W), None, 0, None, None, 0, ptr(out), 8, 10, 12, 8, _stream()) == 1
