@@ -54,6 +54,10 @@ PROTOTYPES = {
     "mp_idgnn_agg_f32": (C.c_int, [_p, _p, _p, _i64, _p, _pi32, _p, _i64, _p, _i64, _p, _i64, _i32,
                                    _p, _sz, _p]),
     "mp_spmm_max_bwd_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _i64, _p]),
+    "mp_bn_ws_bytes": (C.c_int, [_i64, _i32, _psz]),
+    "mp_bn_train_fwd_f32": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _f32, C.c_int, _p, _i64, _p, _p, _p, _p, _sz, _p]),
+    "mp_bn_train_bwd_f32": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _p, _i64, _p, _p, _p,
+                                      _sz, _p]),
     "mp_dense_config": (C.c_int, [C.c_int]),
     "mp_dense_fused_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _p, _p, C.c_int, _p, _i64, _i64, _i32, _i32, _p]),
     "mp_dense_wgrad_ws_bytes": (C.c_int, [_i64, _i32, _i32, _psz]),

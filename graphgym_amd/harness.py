@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import layers as L
+from . import nn as mpnn
 from .config import cfg
 from .registry import layer_dict
 
@@ -42,8 +43,9 @@ _TF_LAYER = {
 
 def _keras_gin_mlp(dim_in, dim):
     # main_zd.py:181-186: Dense(d, relu) -> Dense(d) -> BatchNormalization -> relu
+    # BatchNormalization + relu run as one engine op (graphgym_amd.nn.BatchNorm1d(relu=True))
     return nn.Sequential(nn.Linear(dim_in, dim), nn.ReLU(), nn.Linear(dim, dim),
-                         nn.BatchNorm1d(dim, eps=1e-3, momentum=0.01), nn.ReLU())
+                         mpnn.BatchNorm1d(dim, eps=1e-3, momentum=0.01, relu=True))
 
 
 class TfgNodeModel(nn.Module):
@@ -103,11 +105,12 @@ class GeneralLayer(nn.Module):
         has_bn = has_bn and cfg.gnn.batchnorm
         self.layer = layer_dict[name](dim_in, dim_out, bias=not has_bn, **kwargs)
         post = []
-        if has_bn:
-            post.append(nn.BatchNorm1d(dim_out, eps=cfg.bn.eps, momentum=cfg.bn.mom))
+        fuse_relu = has_bn and has_act and cfg.gnn.act == "relu" and not cfg.gnn.dropout > 0
+        if has_bn:   # BN (+ the ReLU right behind it) on the engine's HBM-bound passes
+            post.append(mpnn.BatchNorm1d(dim_out, eps=cfg.bn.eps, momentum=cfg.bn.mom, relu=fuse_relu))
         if cfg.gnn.dropout > 0:
             post.append(nn.Dropout(p=cfg.gnn.dropout, inplace=cfg.mem.inplace))
-        if has_act:
+        if has_act and not fuse_relu:
             post.append(nn.ReLU() if cfg.gnn.act == "relu" else getattr(nn, cfg.gnn.act)())
         self.post_layer = nn.Sequential(*post)
 

@@ -788,8 +788,9 @@ class GAT(IDGAT):
 # ---- GraphGym-style wrappers for the TF-family keys of config/*_tf/*.yaml:29 ----
 def _tf_gin_mlp(dim_in, dim_out):
     # main_zd.py:181-186 / 214-225: Dense(d, relu) -> Dense(d) -> BatchNorm -> relu
+    from .nn import BatchNorm1d as _BN
     return nn.Sequential(nn.Linear(dim_in, dim_out), nn.ReLU(), nn.Linear(dim_out, dim_out),
-                         nn.BatchNorm1d(dim_out, eps=1e-3, momentum=0.01), nn.ReLU())
+                         _BN(dim_out, eps=1e-3, momentum=0.01, relu=True))
 
 
 class _TfBatchLayer(nn.Module):

@@ -229,6 +229,26 @@ int mp_spmm_max_bwd_f32(const int32_t* col, const float* val, const int32_t* arg
                         float* dX, int64_t ldx, mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
+ * BatchNorm1d over the node axis in training mode with the activation  *
+ * fused (K20 / SURVEY §8f rank 3): graphgym/models/layer.py:26-35,      *
+ * keras BatchNormalization of main_zd.py:181-186.                       *
+ *   fwd: mean / biased var over the N rows, y = act((x - mean) * invstd *
+ *        * gamma + beta); var_unbiased feeds the running statistics.    *
+ *   bwd: g = dy * [y > 0] (y NULL = no activation); dgamma, dbeta, dx.  *
+ * Column sums are combined in double precision in a fixed order.        *
+ * ------------------------------------------------------------------ */
+int mp_bn_ws_bytes(int64_t N, int32_t d, size_t* bytes_host);
+int mp_bn_train_fwd_f32(const float* x, int64_t ldx, int64_t N, int32_t d,
+                        const float* gamma, const float* beta, float eps, int relu,
+                        float* y, int64_t ldy, float* mean, float* invstd, float* var_unbiased,
+                        void* ws, size_t ws_bytes, mp_stream_t stream);
+int mp_bn_train_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy,
+                        const float* x, int64_t ldx, int64_t N, int32_t d,
+                        const float* gamma, const float* mean, const float* invstd,
+                        float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                        void* ws, size_t ws_bytes, mp_stream_t stream);
+
+/* ------------------------------------------------------------------ *
  * Dense transform after the aggregation, fused (K10 / K11 / K15):       *
  *   out = act( P @ W [+ Q @ W_id] + bias )                              *
  * P, Q [M, F] (ldp, ldq), W, W_id [F, d] row-major contiguous, bias [d] *

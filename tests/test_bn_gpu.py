@@ -1,0 +1,52 @@
+"""graphgym_amd.nn.BatchNorm1d (training mode on the engine's kernels) vs torch.nn.BatchNorm1d in float64 on
+the host: outputs, input / affine gradients, running statistics; with and without the fused ReLU; widths that
+take the vector and the scalar paths; a column with a large mean (shifted sums must not cancel)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,d", [(2, 4), (1000, 256), (4097, 100), (333, 7), (20000, 512), (50000, 64)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm_training_parity(dev, N, d, relu):
+    from graphgym_amd.nn import BatchNorm1d
+    g = torch.Generator().manual_seed(N + d)
+    x = torch.randn(N, d, generator=g) * (torch.rand(d, generator=g) * 3 + 0.1) + torch.randn(d, generator=g) * 5
+    x[:, 0] += 1000.0                                              # large mean, unit variance
+    dy = torch.randn(N, d, generator=g)
+    ref = torch.nn.BatchNorm1d(d, eps=1e-5, momentum=0.1).double()
+    ours = BatchNorm1d(d, eps=1e-5, momentum=0.1, relu=relu).to(dev)
+    with torch.no_grad():
+        w, b = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g)
+        ref.weight.copy_(w); ref.bias.copy_(b); ours.weight.copy_(w); ours.bias.copy_(b)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.double())
+    xg = x.to(dev).requires_grad_(True)
+    y = ours(xg)
+    y.backward(dy.to(dev))
+
+    def close(a, r, tol):
+        a, r = a.detach().cpu().double(), r.detach().double()
+        assert float((a - r).abs().max()) <= tol * max(1.0, float(r.abs().max())), float((a - r).abs().max())
+    close(y, yr, 2e-5)
+    close(xg.grad, xr.grad, 1e-4)
+    close(ours.weight.grad, ref.weight.grad, 1e-4)
+    close(ours.bias.grad, ref.bias.grad, 1e-4)
+    close(ours.running_mean, ref.running_mean, 1e-5)
+    close(ours.running_var, ref.running_var, 1e-4)
+    assert int(ours.num_batches_tracked) == 1
+    ours.eval(); ref.eval()                                        # eval: running statistics, library path
+    ye = ours(x.to(dev))
+    yre = torch.relu(ref(x.double())) if relu else ref(x.double())
+    close(ye, yre, 1e-4)
+
+
+def test_state_dict_interchanges_with_torch(dev):
+    from graphgym_amd.nn import BatchNorm1d
+    a, b = BatchNorm1d(16, relu=True), torch.nn.BatchNorm1d(16)
+    assert set(a.state_dict()) == set(b.state_dict())
+    b.load_state_dict(a.state_dict())
