@@ -668,6 +668,11 @@ class IDSAGE(_KerasLike):
         x, edge_index, id_index, edge_weight = _unpack(inputs, self.with_id)
         self._maybe_build(x)
         g = get_graph(holder, edge_index, x.size(0), dst_row=0, loops="none", edge_weight=edge_weight)
+        if id_index is None and self.concat and (self.activation is None or _is_relu(self.activation)):
+            # [x W_s ‖ mean W_n] + b -> act written as one buffer by two kernel launches (no cat / bias / act passes)
+            h = ops.concat_dense(x, ops.spmm(g, x, "mean"), self.self_kernel, self.neighbor_kernel, self.bias,
+                                 relu=self.activation is not None)
+            return F.normalize(h, p=2, dim=-1) if self.normalize else h
         neighbor_msg = ops.dense_fused(ops.spmm(g, x, "mean"), self.neighbor_kernel)
         h = ops.dense_fused(x, self.self_kernel)
         if id_index is not None:

@@ -249,6 +249,62 @@ class _DenseFused(torch.autograd.Function):
         return dP, dW, dQ, dWid, db, None
 
 
+def _dense_into(out_view, P, W, bias, relu):
+    """out_view[:, :] = act(P @ W + bias) written in place through the kernel's output leading dimension"""
+    L = lib()
+    M, F = P.shape
+    d = W.size(1)
+    Wc = W.contiguous()
+    b = None if bias is None else bias.contiguous()
+    with torch.cuda.device(P.device):
+        check(L.mp_dense_fused_f32(ptr(P), P.stride(0), ptr(Wc), None, 0, None, ptr(b),
+                                   _lib.ACT_RELU if relu else _lib.ACT_NONE, ptr(out_view), out_view.stride(0), M, F, d,
+                                   _stream()), "mp_dense_fused_f32")
+
+
+class _ConcatDense(torch.autograd.Function):
+    """out = act([x @ Ws ‖ m @ Wn] + bias): both halves written straight into one buffer (no cat, no separate
+    bias / activation passes) — the combine step of tfg MeanGraphSage / IDSAGE.call (TfgIDLayer.py:100-117)"""
+    @staticmethod
+    def forward(ctx, x, m, Ws, Wn, bias, relu):
+        x, m = _f32c(x, "x"), _f32c(m, "m")
+        ku, kn = Ws.size(1), Wn.size(1)
+        out = torch.empty((x.size(0), ku + kn), dtype=torch.float32, device=x.device)
+        b = None if bias is None else bias.detach()
+        _dense_into(out[:, :ku], x, Ws.detach(), None if b is None else b[:ku], relu)
+        _dense_into(out[:, ku:], m, Wn.detach(), None if b is None else b[ku:], relu)
+        ctx.relu, ctx.ku, ctx.has_bias = relu, ku, bias is not None
+        ctx.save_for_backward(x, m, Ws, Wn, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, m, Ws, Wn, out = ctx.saved_tensors
+        ku = ctx.ku
+        if ctx.relu:
+            g = g * (out > 0)
+        g = g.contiguous()
+        gs, gn = g[:, :ku], g[:, ku:]                      # strided views: the kernels take leading dimensions
+
+        def times_wt(gv, Wm):
+            r = _raw_dense_fused(gv, Wm.detach().t().contiguous(), None, None, None, False)
+            return r if r is not None else gv @ Wm.t()
+
+        def wgrad(Xm, gv):
+            r = _raw_dense_wgrad(Xm, gv)
+            return r if r is not None else Xm.t() @ gv
+        dx = times_wt(gs, Ws) if ctx.needs_input_grad[0] else None
+        dm = times_wt(gn, Wn) if ctx.needs_input_grad[1] else None
+        dWs = wgrad(x, gs) if ctx.needs_input_grad[2] else None
+        dWn = wgrad(m, gn) if ctx.needs_input_grad[3] else None
+        db = g.sum(0) if ctx.has_bias else None
+        return dx, dm, dWs, dWn, db, None
+
+
+def concat_dense(x, m, Ws, Wn, bias=None, relu=False):
+    return _ConcatDense.apply(x, m, Ws, Wn, bias, bool(relu))
+
+
 def dense_fused(P, W, Q=None, W_id=None, bias=None, relu=False):
     """act(P @ W [+ Q @ W_id] + bias) in one kernel (mp_dense_fused_f32); gradients through library GEMMs"""
     return _DenseFused.apply(P, W, Q, W_id, bias, bool(relu))
