@@ -40,6 +40,7 @@ PROTOTYPES = {
     "mp_csr_transpose": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mp_csr_degree": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _p, _p]),
     "mp_gcn_norm_edges": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _p, _p, _p]),
+    "mp_csr_scale_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "mp_mark_id_sources": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _p, _p]),
     "mp_spmm_plan_config": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mp_spmm_kernel_config": (C.c_int, [C.c_int, C.c_int]),

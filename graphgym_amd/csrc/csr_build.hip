@@ -242,6 +242,25 @@ __global__ __launch_bounds__(kBlock) void norm_edges_kernel(const int32_t* __res
   }
 }
 
+// val_out[e] = rs[row(e)] * val[e] * cs[col(e)]   (either scale may be null = ones)
+__global__ __launch_bounds__(kBlock) void scale_edges_kernel(const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col,
+                                                             const float* __restrict__ val,
+                                                             const float* __restrict__ rs,
+                                                             const float* __restrict__ cs, int64_t N,
+                                                             float* val_out) {
+  const int sub = threadIdx.x % kRowLanes;
+  const int64_t groups = (int64_t)gridDim.x * (kBlock / kRowLanes);
+  for (int64_t r = (int64_t)blockIdx.x * (kBlock / kRowLanes) + threadIdx.x / kRowLanes; r < N; r += groups) {
+    const int s = rowptr[r], e = rowptr[r + 1];
+    const float dr = rs ? rs[r] : 1.f;
+    for (int k = s + sub; k < e; k += kRowLanes) {
+      const float w = val ? val[k] : 1.f;
+      val_out[k] = dr * w * (cs ? cs[col[k]] : 1.f);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void set_flags_kernel(const int64_t* __restrict__ idx, int64_t n,
                                                            int64_t N, uint8_t* flag) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -441,6 +460,16 @@ int mp_gcn_norm_edges(const int32_t* rowptr, const int32_t* col, const float* va
                        dinv_out, N, val_out);
     MP_LAUNCH_CHECK();
   }
+  return MP_OK;
+}
+
+int mp_csr_scale_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int64_t nnz,
+                     const float* row_scale, const float* col_scale, float* val_out, mp_stream_t stream) {
+  if (!rowptr || N < 0 || nnz < 0 || (nnz > 0 && (!col || !val_out))) return MP_ERR_INVALID_ARG;
+  if (N == 0 || nnz == 0) return MP_OK;
+  hipLaunchKernelGGL(scale_edges_kernel, dim3(flat_grid(N * kRowLanes)), dim3(kBlock), 0, as_stream(stream), rowptr,
+                     col, val, row_scale, col_scale, N, val_out);
+  MP_LAUNCH_CHECK();
   return MP_OK;
 }
 

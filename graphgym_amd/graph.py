@@ -249,6 +249,17 @@ class CSRGraph:
         g.dinv = dinv[:N]
         return g
 
+    def scaled(self, row_scale=None, col_scale=None):
+        """diag(row_scale) @ A @ diag(col_scale) on the stored entries (sparse_adj.py:110-119)"""
+        L = lib()
+        out = torch.empty(max(self.nnz, 1), dtype=torch.float32, device=self.device)
+        rs = None if row_scale is None else row_scale.to(torch.float32).contiguous()
+        cs = None if col_scale is None else col_scale.to(torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            check(L.mp_csr_scale_f32(ptr(self.rowptr), ptr(self.col), ptr(self.val), self.num_nodes, self.nnz,
+                                     ptr(rs), ptr(cs), ptr(out), _stream()), "mp_csr_scale_f32")
+        return self.with_values(out[:self.nnz])
+
     def mark_ids(self, id_index):
         """col with the sign bit set on entries whose source is an identity node; cached per index tensor
         (the mark depends only on the pattern, so graphs sharing a pattern share it)"""

@@ -136,6 +136,12 @@ int mp_gcn_norm_edges(const int32_t* rowptr, const int32_t* col, const float* va
                       int64_t N, int64_t nnz, int deg_axis,
                       float* val_out, float* dinv_out, mp_stream_t stream);
 
+/* diagonal scalings of the stored entries (A3): val_out[e] = row_scale[row] * val[e] * col_scale[col];
+ * either scale NULL = ones.  diag @ A = SparseAdj.rmatmul_diag / diag_sparse_matmul (sparse_adj.py:116-119,
+ * sparse_ops.py:11-12); A @ diag = matmul_diag / sparse_diag_matmul (sparse_adj.py:110-113, sparse_ops.py:6-7) */
+int mp_csr_scale_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int64_t nnz,
+                     const float* row_scale, const float* col_scale, float* val_out, mp_stream_t stream);
+
 /* mark entries whose SOURCE is an identity node: col_out[e] = col[e] | 0x80000000
  * when is_id[col[e]] != 0.  is_id: [N] uint8 scratch filled from id_index. */
 int mp_mark_id_sources(const int32_t* col, int64_t nnz, const int64_t* id_index,
