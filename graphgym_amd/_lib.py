@@ -40,6 +40,8 @@ PROTOTYPES = {
     "mp_csr_transpose": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mp_csr_degree": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _p, _p]),
     "mp_gcn_norm_edges": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _p, _p, _p]),
+    "mp_stream_create_cu_mask": (C.c_int, [_p, C.c_int, _p]),
+    "mp_stream_destroy": (C.c_int, [_p]),
     "mp_csr_scale_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "mp_mark_id_sources": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _p, _p]),
     "mp_spmm_plan_config": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -59,6 +61,8 @@ PROTOTYPES = {
     "mp_bn_train_fwd_f32": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _f32, C.c_int, _p, _i64, _p, _p, _p, _p, _sz, _p]),
     "mp_bn_train_bwd_f32": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _p, _i64, _p, _p, _p,
                                       _sz, _p]),
+    "mp_agg_dense_f32": (C.c_int, [_p, _p, _p, _i64, _p, _i64, _i32, _p, _i64, C.c_float, _p, _i64, _i32, _p, C.c_int,
+                                   _p, _i64, _p, _i64, _p]),
     "mp_dense_config": (C.c_int, [C.c_int]),
     "mp_dense_fused_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _p, _p, C.c_int, _p, _i64, _i64, _i32, _i32, _p]),
     "mp_dense_wgrad_ws_bytes": (C.c_int, [_i64, _i32, _i32, _psz]),

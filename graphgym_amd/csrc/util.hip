@@ -50,6 +50,20 @@ int mp_copy_probe_f32(const float* src, float* dst, int64_t n, mp_stream_t strea
   return MP_OK;
 }
 
+int mp_stream_create_cu_mask(const uint32_t* mask, int n_words, mp_stream_t* stream) {
+  if (!mask || n_words <= 0 || !stream) return MP_ERR_INVALID_ARG;
+  hipStream_t s = nullptr;
+  MP_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask));
+  *stream = (mp_stream_t)s;
+  return MP_OK;
+}
+
+int mp_stream_destroy(mp_stream_t stream) {
+  if (!stream) return MP_ERR_INVALID_ARG;
+  MP_HIP(hipStreamDestroy(mp::as_stream(stream)));
+  return MP_OK;
+}
+
 const char* mp_status_str(int status) {
   switch (status) {
     case MP_OK: return "ok";

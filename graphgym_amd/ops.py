@@ -64,7 +64,7 @@ class _SpMM(torch.autograd.Function):
         g = ctx.g
         dy = dy.contiguous()
         if ctx.relu:
-            dy = dy * (y > 0)
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)    # one vectorised pass
         dbias = dy.sum(0) if ctx.has_bias else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -190,6 +190,32 @@ def _raw_dense_fused(P, W, Q, W_id, bias, relu):
     return out
 
 
+FUSED_WIDTHS = (64, 128, 256)
+
+
+def agg_dense_supported(g, x, W):
+    """shapes the one-kernel aggregate -> transform takes (mp_agg_dense_f32)"""
+    return (x.size(1) in FUSED_WIDTHS and W.size(1) % 2 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and g.nnz > 0)
+
+
+def _raw_agg_dense(g, x, W, bias=None, relu=False, S=None, self_scale=0.0, want_P=False):
+    """out = act((A x + self_scale * S) W + bias) in one launch; returns (out, P or None)"""
+    L = lib()
+    N, F, d = g.num_nodes, x.size(1), W.size(1)
+    Wc = W.contiguous()
+    b = None if bias is None else bias.contiguous()
+    out = torch.empty((N, d), dtype=torch.float32, device=x.device)
+    P = torch.empty((N, F), dtype=torch.float32, device=x.device) if want_P else None
+    with torch.cuda.device(x.device):
+        check(L.mp_agg_dense_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val), N, ptr(x), x.stride(0), F,
+                                 ptr(S), S.stride(0) if S is not None else 0, float(self_scale), ptr(Wc),
+                                 Wc.stride(0), d, ptr(b), _lib.ACT_RELU if relu else _lib.ACT_NONE,
+                                 ptr(P), P.stride(0) if P is not None else 0, ptr(out), out.stride(0), _stream()),
+              "mp_agg_dense_f32")
+    return out, P
+
+
 def _raw_dense_wgrad(P, G):
     """P^T @ G on the engine's split-K MFMA kernel (None when the shape is outside it)"""
     L = lib()
@@ -232,7 +258,7 @@ class _DenseFused(torch.autograd.Function):
     def backward(ctx, g):
         P, W, Q, W_id, out = ctx.saved_tensors
         if ctx.relu:
-            g = g * (out > 0)
+            g = torch.ops.aten.threshold_backward(g, out, 0.0)
         g = g.contiguous()
 
         def times_wt(Wm):   # g @ Wm^T on the engine's kernel when the shape allows, else the library
@@ -282,7 +308,7 @@ class _ConcatDense(torch.autograd.Function):
         x, m, Ws, Wn, out = ctx.saved_tensors
         ku = ctx.ku
         if ctx.relu:
-            g = g * (out > 0)
+            g = torch.ops.aten.threshold_backward(g, out, 0.0)
         g = g.contiguous()
         gs, gn = g[:, :ku], g[:, ku:]                      # strided views: the kernels take leading dimensions
 

@@ -69,6 +69,10 @@ int mp_version(void);
 int mp_copy_probe_f32(const float* src, float* dst, int64_t n, mp_stream_t stream);
 /* read-only stream of n floats; sink must hold 256 * 8 * 256 floats (one per launched lane) */
 int mp_read_probe_f32(const float* src, int64_t n, float* sink, mp_stream_t stream);
+/* a stream restricted to the compute units set in mask (n_words x 32 bits; hipExtStreamCreateWithCUMask):
+ * lets a caller run the HBM-bound aggregation and the MFMA-bound transform side by side on disjoint CUs */
+int mp_stream_create_cu_mask(const uint32_t* mask, int n_words, mp_stream_t* stream);
+int mp_stream_destroy(mp_stream_t stream);
 const char* mp_status_str(int status);
 /* text of the last failing HIP call on this thread ("" if none) */
 const char* mp_last_hip_error(void);
@@ -253,6 +257,22 @@ int mp_bn_train_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t l
                         const float* gamma, const float* mean, const float* invstd,
                         float* dx, int64_t lddx, float* dgamma, float* dbeta,
                         void* ws, size_t ws_bytes, mp_stream_t stream);
+
+/* ------------------------------------------------------------------ *
+ * Aggregate -> transform in one kernel                                *
+ * ------------------------------------------------------------------ */
+/* out[N, d_out] = act( (A X + self_scale * S) W + bias ): SparseAdj.matmul (sparse_adj.py:91-97) followed by
+ * the layer's kernel product (gcn_id in the aggregate-first order, TfgIDLayer.py:510-523; GIN's
+ * (1 + eps) x + sum -> first Linear, idconv.py:371-399, TfgIDLayer.py:447-456) without the [N, F] intermediate
+ * going through HBM: a workgroup reduces a 32-row tile into LDS and multiplies it by W on the matrix cores
+ * while the other workgroups of the compute unit gather.  Sum reduction, stored values (val NULL = ones).
+ * F must be 64, 128 or 256 and d_out even (MP_ERR_UNSUPPORTED otherwise: use mp_spmm_csr_f32 +
+ * mp_dense_fused_f32).  P (optional, [N, F]) receives the aggregated rows (kept for the weight gradient).
+ * No plan, no workspace; bitwise reproducible. */
+int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, const float* X,
+                     int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale, const float* W,
+                     int64_t ldw, int32_t d_out, const float* bias, int act, float* P, int64_t ldp, float* out,
+                     int64_t ldo, mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * Dense transform after the aggregation, fused (K10 / K11 / K15):       *
