@@ -61,7 +61,8 @@ PROTOTYPES = {
     "mp_bn_train_fwd_f32": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _f32, C.c_int, _p, _i64, _p, _p, _p, _p, _sz, _p]),
     "mp_bn_train_bwd_f32": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _p, _i64, _p, _p, _p,
                                       _sz, _p]),
-    "mp_agg_dense_f32": (C.c_int, [_p, _p, _p, _i64, _p, _i64, _i32, _p, _i64, C.c_float, _p, _i64, _i32, _p, C.c_int,
+    "mp_fused_config": (C.c_int, [C.c_int, C.c_int]),
+    "mp_agg_dense_f32": (C.c_int, [_p, _p, _p, _i64, C.c_int, _p, _i64, _i32, _p, _i64, C.c_float, _p, _i64, _i32, _p, C.c_int,
                                    _p, _i64, _p, _i64, _p]),
     "mp_dense_config": (C.c_int, [C.c_int]),
     "mp_dense_fused_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _p, _p, C.c_int, _p, _i64, _i64, _i32, _i32, _p]),

@@ -35,17 +35,25 @@ struct FusedArgs {
   const float* bias; int32_t act;
   float* P; int64_t ldp;
   float* out; int64_t ldo; int32_t dout;
+  int32_t mean;   // rows are divided by their entry count (applied to the saved P rows and in the output epilogue)
 };
 
 constexpr int kTileRows = 32;
 
-template <int W, bool WEIGHTED, int U>
+// VAR bits (mp_fused_config, tuning experiments): 1 = non-temporal stores of out; W fragments fetched
+// 6 (bit 2), 4 (bit 16), 2 (bit 32) K groups ahead instead of 1
+template <int W, bool WEIGHTED, int U, int VAR>
 __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
+  constexpr bool NT_OUT = VAR & 1;
+  constexpr int PF = (VAR & 2) ? 6 : ((VAR & 16) ? 4 : ((VAR & 32) ? 2 : 1));
+  constexpr bool SKIP_MFMA = VAR & 4;     // timing diagnostics only (results are wrong): phase A alone
+  constexpr bool SKIP_GATHER = VAR & 8;   //                                              phase B alone
   constexpr int F = kWave * W;
   constexpr int LDT = F + 4;   // row stride of the tile: 16-byte aligned rows, conflict-free b128 fragment reads
   __shared__ __attribute__((aligned(16))) float T[kTileRows][LDT];
   __shared__ __attribute__((aligned(16))) float carry[kWavesPerBlock - 1][F];
   __shared__ int carry_row[kWavesPerBlock];
+  __shared__ float inv_deg[kTileRows];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -70,6 +78,10 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
   // ---- phase A: this wave's run of entries ----
   // lane i (<= 32) holds the start of tile row i (rows past the end of the matrix are empty)
   const int rp_v = lane <= kTileRows ? a.rowptr[min(R0 + lane, R1)] : INT_MAX;
+  if (a.mean && wave == 0) {   // 1 / (entries of the row): lane i sees the starts of rows i and i + 1
+    const int nxt = __shfl_down(rp_v, 1, kWave);
+    if (lane < kTileRows) inv_deg[lane] = nxt > rp_v ? 1.0f / (float)(nxt - rp_v) : 0.f;
+  }
   const int E0 = bcast_i(rp_v, 0);
   const int E1 = bcast_i(rp_v, kTileRows);
   const int q = (E1 - E0 + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
   if (lane == 0) carry_row[wave] = cont ? first_rl : -1;
   __syncthreads();   // T initialised
 
-  if (es < ee) {
+  if (es < ee && !SKIP_GATHER) {
     const float* __restrict__ xlane = a.X + lane * W;
     int rl = first_rl;
     int rend = bcast_i(rp_v, rl + 1);
@@ -154,9 +166,11 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
     constexpr int VPR = F / 4;
     for (int i = tid; i < kTileRows * VPR; i += kBlock) {
       const int m = i / VPR, c = (i % VPR) * 4;
-      if (R0 + m < R1)
-        __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(&T[m][c]),
-                                    reinterpret_cast<f32x4*>(a.P + (int64_t)(R0 + m) * a.ldp + c));
+      if (R0 + m < R1) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&T[m][c]);
+        if (a.mean) v *= inv_deg[m];
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.P + (int64_t)(R0 + m) * a.ldp + c));
+      }
     }
   }
 
@@ -166,6 +180,10 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
   // 32-column accumulator tiles interleave columns (tile t holds columns n0 + 2 n + t): one 8-byte load
   // feeds both tiles and every output row is stored as 256 contiguous bytes per half-wave.
   const int fr = lane & 31, kk = lane >> 5;
+  if constexpr (SKIP_MFMA) {
+    if (T[fr][kk] == 12345.678f) a.out[0] = 1.f;   // keep phase A alive
+    return;
+  }
   for (int cb = 0; cb < a.dout; cb += 64 * kWavesPerBlock) {
     const int n0 = cb + wave * 64;
     if (n0 >= a.dout) break;                       // wave-uniform
@@ -175,46 +193,78 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    f32x2 bq[2][4];
+    // ring of PF + 1 register slots: the fragments of group g + PF are requested before the MFMAs of group g.
+    // W comes from L2, but under the gather traffic of the other workgroups an L2 hit takes on the order of a
+    // microsecond while one group's MFMAs take 0.2 us, so the distance has to cover several groups.
+    f32x2 bq[PF + 1][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bq[0][j] = *reinterpret_cast<const f32x2*>(wp + (int64_t)j * a.ldw);
-    auto step = [&](int g, auto curc) {
-      constexpr int cur = decltype(curc)::value;
-      if (g + 1 < F / 8) {
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[p][j] = *reinterpret_cast<const f32x2*>(wp + (int64_t)(8 * p + j) * a.ldw);
+#pragma unroll
+    for (int g = 0; g < F / 8; ++g) {      // fully unrolled: every slot index is a constant
+      const int cur = g % (PF + 1), nxt = (g + PF) % (PF + 1);
+      if (g + PF < F / 8) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          bq[cur ^ 1][j] = *reinterpret_cast<const f32x2*>(wp + (int64_t)(8 * (g + 1) + j) * a.ldw);
+          bq[nxt][j] = *reinterpret_cast<const f32x2*>(wp + (int64_t)(8 * (g + PF) + j) * a.ldw);
       }
+      __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (the scheduler would sink them)
       const f32x4 av = *reinterpret_cast<const f32x4*>(&T[fr][8 * g + 4 * kk]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bq[cur][j][0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bq[cur][j][1], acc1, 0, 0, 0);
       }
-    };
-    for (int g = 0; g < F / 8; g += 2) {
-      step(g, std::integral_constant<int, 0>());
-      step(g + 1, std::integral_constant<int, 1>());
+      __builtin_amdgcn_sched_barrier(0);
     }
     f32x2 bv = {0.f, 0.f};
     if (a.bias != nullptr && col_ok) bv = *reinterpret_cast<const f32x2*>(a.bias + cpair);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = R0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-      f32x2 o = {acc0[r] + bv[0], acc1[r] + bv[1]};
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * kk;
+      const int row = R0 + rl;
+      const float sc = a.mean ? inv_deg[rl] : 1.f;
+      f32x2 o = {fmaf(acc0[r], sc, bv[0]), fmaf(acc1[r], sc, bv[1])};
       if (a.act == MP_ACT_RELU) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); }
-      if (col_ok && row < R1) *reinterpret_cast<f32x2*>(a.out + (int64_t)row * a.ldo + cpair) = o;
+      if (col_ok && row < R1) {
+        if constexpr (NT_OUT) __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(a.out + (int64_t)row * a.ldo + cpair));
+        else *reinterpret_cast<f32x2*>(a.out + (int64_t)row * a.ldo + cpair) = o;
+      }
     }
   }
 }
 
-template <int W>
-static int launch_fused(const FusedArgs& a, hipStream_t st) {
+static int g_fused_var = 32;
+static int g_fused_u = 8;
+
+template <int W, int U, int VAR>
+static int launch_fused_v(const FusedArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)ceil_div(a.N, kTileRows)), block(kBlock);
-  if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, 8>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((agg_dense_kernel<W, false, 8>), grid, block, 0, st, a);
+  if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, U, VAR>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((agg_dense_kernel<W, false, U, VAR>), grid, block, 0, st, a);
   MP_LAUNCH_CHECK();
   return MP_OK;
+}
+
+template <int W>
+static int launch_fused(const FusedArgs& a, hipStream_t st) {
+  if constexpr (W == 4) {   // the tuning variants exist for the 256-wide case only
+    if (g_fused_u == 4) return launch_fused_v<4, 4, 32>(a, st);
+    if (g_fused_u == 16) return launch_fused_v<4, 16, 32>(a, st);
+    switch (g_fused_var) {
+      case 1: return launch_fused_v<4, 8, 1>(a, st);
+      case 2: return launch_fused_v<4, 8, 2>(a, st);
+      case 4: return launch_fused_v<4, 8, 4>(a, st);
+      case 16: return launch_fused_v<4, 8, 16>(a, st);
+      case 32: return launch_fused_v<4, 8, 32>(a, st);
+      case 36: return launch_fused_v<4, 8, 36>(a, st);
+      case 40: return launch_fused_v<4, 8, 40>(a, st);
+      case 8: return launch_fused_v<4, 8, 8>(a, st);
+      default: break;
+    }
+  }
+  return launch_fused_v<W, 8, 0>(a, st);
 }
 
 }  // namespace mp
@@ -223,13 +273,22 @@ using namespace mp;
 
 extern "C" {
 
-int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, const float* X,
-                     int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale, const float* W,
+int mp_fused_config(int rows_in_flight, int variant_bits) {
+  if ((rows_in_flight != 4 && rows_in_flight != 8 && rows_in_flight != 16) || variant_bits < 0 || variant_bits > 63) return MP_ERR_INVALID_ARG;
+  g_fused_u = rows_in_flight;
+  g_fused_var = variant_bits;
+  return MP_OK;
+}
+
+int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
+                     const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale, const float* W,
                      int64_t ldw, int32_t d_out, const float* bias, int act, float* P, int64_t ldp, float* out,
                      int64_t ldo, mp_stream_t stream) {
   if (!rowptr || !X || !W || !out || N < 0 || F <= 0 || d_out <= 0) return MP_ERR_INVALID_ARG;
   if (ldx < F || ldw < d_out || ldo < d_out || (S && lds < F) || (P && ldp < F)) return MP_ERR_INVALID_ARG;
   if (act != MP_ACT_NONE && act != MP_ACT_RELU) return MP_ERR_INVALID_ARG;
+  if (reduce != MP_SUM && reduce != MP_MEAN) return MP_ERR_INVALID_ARG;
+  if (reduce == MP_MEAN && S) return MP_ERR_INVALID_ARG;
   if (F != 64 && F != 128 && F != 256) return MP_ERR_UNSUPPORTED;
   if (d_out % 2) return MP_ERR_UNSUPPORTED;
   if (N >= INT32_MAX - kTileRows) return MP_ERR_UNSUPPORTED;
@@ -243,7 +302,7 @@ int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val
   FusedArgs a;
   a.rowptr = rowptr; a.col = col; a.val = val; a.N = (int32_t)N;
   a.X = X; a.ldx = ldx; a.S = S; a.lds = lds; a.self_scale = self_scale;
-  a.Wm = W; a.ldw = ldw; a.bias = bias; a.act = act; a.P = P; a.ldp = ldp; a.out = out; a.ldo = ldo; a.dout = d_out;
+  a.Wm = W; a.ldw = ldw; a.bias = bias; a.act = act; a.P = P; a.ldp = ldp; a.out = out; a.ldo = ldo; a.dout = d_out; a.mean = reduce == MP_MEAN;
   switch (w) {
     case 4: return launch_fused<4>(a, as_stream(stream));
     case 2: return launch_fused<2>(a, as_stream(stream));

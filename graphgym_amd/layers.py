@@ -97,9 +97,28 @@ def _id_branch(h, x, id_index, weight_id):
 
 
 def _pick_order(mode, dim_in, dim_out):
+    """'auto': gather at the narrower width; at equal widths the one-kernel aggregate -> transform
+    (ops.agg_dense) hides the MFMA work behind the gathers, so aggregate first when it applies"""
     if mode == "auto":
-        return "aggregate_first" if dim_in < dim_out else "transform_first"
+        if dim_in < dim_out or (dim_in == dim_out and dim_in in ops.FUSED_WIDTHS):
+            return "aggregate_first"
+        return "transform_first"
     return mode
+
+
+def _fused_mlp_head(mlp, g, x, self_scale):
+    """(1 + eps) x + sum_j x_j followed by an MLP that opens with Linear [-> ReLU]: the combine step and the
+    first Linear (+ ReLU) run as one kernel; returns None when the MLP has another shape"""
+    if not isinstance(mlp, nn.Sequential) or len(mlp) == 0 or type(mlp[0]) is not nn.Linear:
+        return None
+    lin = mlp[0]
+    if not ops.agg_dense_supported(g, x, lin.weight.t()) or x.dtype != torch.float32:
+        return None
+    relu = len(mlp) > 1 and type(mlp[1]) is nn.ReLU
+    h = ops.agg_dense(g, x, lin.weight.t(), bias=lin.bias, relu=relu, self_scale=self_scale)
+    for m in list(mlp)[2 if relu else 1:]:
+        h = m(h)
+    return h
 
 
 # =========================================================================================
@@ -349,6 +368,10 @@ class GINIDConvLayer(nn.Module):
     def forward(self, x, edge_index, id, holder=None):
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         g = get_graph(holder, edge_index, x.size(0), loops=self._loops)
+        if id is None and not self.train_eps:
+            out = _fused_mlp_head(self.nn, g, x, 1.0 + float(self.initial_eps))
+            if out is not None:
+                return out
         h = self._combine(g, x)
         out = self.nn(h)
         if id is not None:
@@ -383,7 +406,7 @@ class GCNConvLayer(nn.Module):
         g = get_graph(holder, edge_index, x.size(0), loops="remaining", norm="row",
                       fill=2.0 if self.improved else 1.0, edge_weight=edge_weight)
         if _pick_order(self.order, self.in_channels, self.out_channels) == "aggregate_first":
-            return ops.dense_fused(ops.spmm(g, x, "sum"), self.weight, bias=self.bias)
+            return ops.agg_dense(g, x, self.weight, bias=self.bias)
         return ops.spmm(g, ops.dense_fused(x, self.weight), "sum", bias=self.bias)
 
 
@@ -622,7 +645,7 @@ class IDGCN(_KerasLike):
                 P, Q = ops.idgnn_aggregate(g, id_index, x)
                 h = ops.dense_fused(P, self.kernel, Q, self.kernel_id, self.bias, relu=relu)
             else:
-                h = ops.dense_fused(ops.spmm(g, x, "sum"), self.kernel, bias=self.bias, relu=relu)
+                h = ops.agg_dense(g, x, self.kernel, bias=self.bias, relu=relu)
             return h if relu else _apply_act(h, self.activation)
         h = ops.dense_fused(x, self.kernel)
         if id_index is not None:
@@ -670,8 +693,8 @@ class IDSAGE(_KerasLike):
         g = get_graph(holder, edge_index, x.size(0), dst_row=0, loops="none", edge_weight=edge_weight)
         if id_index is None and self.concat and (self.activation is None or _is_relu(self.activation)):
             # [x W_s ‖ mean W_n] + b -> act written as one buffer by two kernel launches (no cat / bias / act passes)
-            h = ops.concat_dense(x, ops.spmm(g, x, "mean"), self.self_kernel, self.neighbor_kernel, self.bias,
-                                 relu=self.activation is not None)
+            h = ops.sage_concat(g, x, self.self_kernel, self.neighbor_kernel, self.bias,
+                                relu=self.activation is not None)
             return F.normalize(h, p=2, dim=-1) if self.normalize else h
         neighbor_msg = ops.dense_fused(ops.spmm(g, x, "mean"), self.neighbor_kernel)
         h = ops.dense_fused(x, self.self_kernel)
@@ -708,6 +731,10 @@ class IDGIN(_KerasLike):
     def call(self, inputs, cache=None, training=None, mask=None, holder=None):
         x, edge_index, id_index, _ = _unpack(inputs, self.with_id)   # edge weights ignored (:150-151)
         g = get_graph(holder, edge_index, x.size(0), dst_row=0, loops="none")
+        if id_index is None and not self.train_eps:
+            out = _fused_mlp_head(self.mlp_model, g, x, 1.0 + float(self.eps))
+            if out is not None:
+                return out
         if self.train_eps:
             h = x * (1.0 + self.eps) + ops.spmm(g, x, "sum")
         else:

@@ -7,6 +7,7 @@ C-ABI entry point of libmpengine.so (include/mp_engine.h).
     edge_softmax / sddmm_*       GAT pieces (TfgIDLayer.py:333-355; idconv.py:317-332)
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -194,21 +195,27 @@ FUSED_WIDTHS = (64, 128, 256)
 
 
 def agg_dense_supported(g, x, W):
-    """shapes the one-kernel aggregate -> transform takes (mp_agg_dense_f32)"""
+    """shapes the one-kernel aggregate -> transform takes (mp_agg_dense_f32); MP_FUSED=0 in the environment
+    turns the path off (A/B timing against the two-kernel order)"""
+    if os.environ.get("MP_FUSED", "1") == "0":
+        return False
     return (x.size(1) in FUSED_WIDTHS and W.size(1) % 2 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
             and g.nnz > 0)
 
 
-def _raw_agg_dense(g, x, W, bias=None, relu=False, S=None, self_scale=0.0, want_P=False):
-    """out = act((A x + self_scale * S) W + bias) in one launch; returns (out, P or None)"""
+def _raw_agg_dense(g, x, W, bias=None, relu=False, S=None, self_scale=0.0, want_P=False, reduce=_lib.SUM,
+                   out=None):
+    """out = act((reduce_j w_ij x[j] + self_scale * S) W + bias) in one launch (into the view `out` when given);
+    returns (out, P or None) with P the aggregated rows"""
     L = lib()
     N, F, d = g.num_nodes, x.size(1), W.size(1)
     Wc = W.contiguous()
     b = None if bias is None else bias.contiguous()
-    out = torch.empty((N, d), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((N, d), dtype=torch.float32, device=x.device)
     P = torch.empty((N, F), dtype=torch.float32, device=x.device) if want_P else None
     with torch.cuda.device(x.device):
-        check(L.mp_agg_dense_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val), N, ptr(x), x.stride(0), F,
+        check(L.mp_agg_dense_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val), N, reduce, ptr(x), x.stride(0), F,
                                  ptr(S), S.stride(0) if S is not None else 0, float(self_scale), ptr(Wc),
                                  Wc.stride(0), d, ptr(b), _lib.ACT_RELU if relu else _lib.ACT_NONE,
                                  ptr(P), P.stride(0) if P is not None else 0, ptr(out), out.stride(0), _stream()),
@@ -275,6 +282,59 @@ class _DenseFused(torch.autograd.Function):
         return dP, dW, dQ, dWid, db, None
 
 
+class _AggDense(torch.autograd.Function):
+    """out = act((A x + self_scale * x) W + bias) as one kernel; the backward pass runs the same kernel on the
+    transposed operator: dx = (A' g + self_scale * g) W', dW = P' g with P kept by the forward launch."""
+    @staticmethod
+    def forward(ctx, x, W, bias, g, self_scale, relu):
+        x = _f32c(x, "x")
+        if x.size(0) != g.num_cols:
+            raise ValueError(f"x has {x.size(0)} rows, the operator has {g.num_cols} columns")
+        if g.num_cols != g.num_nodes and self_scale != 0.0:
+            raise ValueError("the self term needs a square operator")
+        need_w = ctx.needs_input_grad[1]
+        out, P = _raw_agg_dense(g, x, W.detach(), None if bias is None else bias.detach(), relu,
+                                S=x if self_scale != 0.0 else None, self_scale=self_scale, want_P=need_w)
+        ctx.g, ctx.self_scale, ctx.relu, ctx.has_bias = g, self_scale, relu, bias is not None
+        ctx.save_for_backward(P, W, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        P, W, out = ctx.saved_tensors
+        gm = gout.contiguous()
+        if ctx.relu:
+            gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
+        db = gm.sum(0) if ctx.has_bias else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            dW = _raw_dense_wgrad(P, gm)
+            if dW is None:
+                dW = P.t() @ gm
+        dx = None
+        if ctx.needs_input_grad[0]:
+            gt = ctx.g.transpose()
+            Wt = W.detach().t().contiguous()
+            S = gm if ctx.self_scale != 0.0 else None
+            if agg_dense_supported(gt, gm, Wt):
+                dx, _ = _raw_agg_dense(gt, gm, Wt, None, False, S=S, self_scale=ctx.self_scale)
+            else:
+                T, _ = _raw_spmm(gt, gm, _lib.SUM, S=S, self_scale=ctx.self_scale)
+                dx = _raw_dense_fused(T, Wt, None, None, None, False)
+                if dx is None:
+                    dx = T @ Wt
+        return dx, dW, db, None, None, None
+
+
+def agg_dense(g, x, W, bias=None, relu=False, self_scale=0.0):
+    """act((sum_{j in N(i)} w_ij x[j] + self_scale * x[i]) W + bias): aggregation and the feature transform
+    that follows it in ONE kernel (mp_agg_dense_f32) when the shapes allow (agg_dense_supported), otherwise
+    the aggregation kernel followed by the fused transform"""
+    if agg_dense_supported(g, x, W) and x.dtype == torch.float32:
+        return _AggDense.apply(x, W, bias, g, float(self_scale), bool(relu))
+    return dense_fused(spmm(g, x, "sum", self_scale=self_scale), W, bias=bias, relu=relu)
+
+
 def _dense_into(out_view, P, W, bias, relu):
     """out_view[:, :] = act(P @ W + bias) written in place through the kernel's output leading dimension"""
     L = lib()
@@ -329,6 +389,63 @@ class _ConcatDense(torch.autograd.Function):
 
 def concat_dense(x, m, Ws, Wn, bias=None, relu=False):
     return _ConcatDense.apply(x, m, Ws, Wn, bias, bool(relu))
+
+
+class _SageConcatFused(torch.autograd.Function):
+    """out = act([x Ws ‖ mean_j(x_j) Wn] + bias) (TfgIDLayer.py:100-117): the self half is one MFMA kernel, the
+    neighbour half is the one-kernel aggregate -> transform writing into the same buffer; the backward pass
+    runs the aggregate -> transform kernel on the transposed mean operator."""
+    @staticmethod
+    def forward(ctx, x, Ws, Wn, bias, g, relu):
+        x = _f32c(x, "x")
+        ku, kn = Ws.size(1), Wn.size(1)
+        out = torch.empty((x.size(0), ku + kn), dtype=torch.float32, device=x.device)
+        b = None if bias is None else bias.detach()
+        _dense_into(out[:, :ku], x, Ws.detach(), None if b is None else b[:ku], relu)
+        _, P = _raw_agg_dense(g, x, Wn.detach(), None if b is None else b[ku:], relu, want_P=ctx.needs_input_grad[2],
+                              reduce=_lib.MEAN, out=out[:, ku:])
+        ctx.g, ctx.relu, ctx.ku, ctx.has_bias = g, relu, ku, bias is not None
+        ctx.save_for_backward(x, P, Ws, Wn, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, P, Ws, Wn, out = ctx.saved_tensors
+        ku = ctx.ku
+        gm = gout.contiguous()
+        if ctx.relu:
+            gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
+        gs, gn = gm[:, :ku], gm[:, ku:]
+
+        def wgrad(Xm, gv):
+            r = _raw_dense_wgrad(Xm, gv)
+            return r if r is not None else Xm.t() @ gv
+        dWs = wgrad(x, gs) if ctx.needs_input_grad[1] else None
+        dWn = wgrad(P, gn) if ctx.needs_input_grad[2] else None
+        db = gm.sum(0) if ctx.has_bias else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _raw_dense_fused(gs, Ws.detach().t().contiguous(), None, None, None, False)
+            if dx is None:
+                dx = gs @ Ws.t()
+            gt = ctx.g.transpose_mean()
+            Wnt = Wn.detach().t().contiguous()
+            if agg_dense_supported(gt, gn, Wnt):
+                dn, _ = _raw_agg_dense(gt, gn, Wnt)
+            else:
+                T, _ = _raw_spmm(gt, gn.contiguous(), _lib.SUM)
+                dn = T @ Wnt
+            dx.add_(dn)
+        return dx, dWs, dWn, db, None, None
+
+
+def sage_concat(g, x, Ws, Wn, bias=None, relu=False):
+    """act([x Ws ‖ mean-aggregate(x) Wn] + bias); one-kernel aggregate -> transform for the neighbour half when
+    the shapes allow, else the aggregation kernel + concat_dense"""
+    if (agg_dense_supported(g, x, Wn) and x.dtype == torch.float32 and Ws.size(1) % 2 == 0
+            and g.num_cols == g.num_nodes):
+        return _SageConcatFused.apply(x, Ws, Wn, bias, g, bool(relu))
+    return concat_dense(x, spmm(g, x, "mean"), Ws, Wn, bias, relu=relu)
 
 
 def dense_fused(P, W, Q=None, W_id=None, bias=None, relu=False):

@@ -265,12 +265,17 @@ int mp_bn_train_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t l
  * the layer's kernel product (gcn_id in the aggregate-first order, TfgIDLayer.py:510-523; GIN's
  * (1 + eps) x + sum -> first Linear, idconv.py:371-399, TfgIDLayer.py:447-456) without the [N, F] intermediate
  * going through HBM: a workgroup reduces a 32-row tile into LDS and multiplies it by W on the matrix cores
- * while the other workgroups of the compute unit gather.  Sum reduction, stored values (val NULL = ones).
+ * while the other workgroups of the compute unit gather.  reduce = MP_SUM | MP_MEAN (mean: rows divided by
+ * their entry count, S must be NULL); stored values (val NULL = ones).
  * F must be 64, 128 or 256 and d_out even (MP_ERR_UNSUPPORTED otherwise: use mp_spmm_csr_f32 +
  * mp_dense_fused_f32).  P (optional, [N, F]) receives the aggregated rows (kept for the weight gradient).
  * No plan, no workspace; bitwise reproducible. */
-int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, const float* X,
-                     int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale, const float* W,
+/* tuning knobs of the kernel below (process-wide): rows in flight per wave (4 | 8), variant bits
+ * (1 = non-temporal stores of out; W fragments fetched 6 / 4 / 2 K groups ahead = 2 / 16 / 32, otherwise 1;
+ * 4 and 8 are timing diagnostics that skip the MFMA / the gather phase and produce WRONG results); defaults 8, 32 */
+int mp_fused_config(int rows_in_flight, int variant_bits);
+int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
+                     const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale, const float* W,
                      int64_t ldw, int32_t d_out, const float* bias, int act, float* P, int64_t ldp, float* out,
                      int64_t ldo, mp_stream_t stream);
 

@@ -62,10 +62,14 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--kinds", default="sage,gin,idgin")
     a = ap.parse_args()
     rank, local, world = D.init_from_env()
     dev = torch.device("cuda", torch.cuda.current_device())
-    for kind, d, centres in (("sage", 256, 0), ("gin", 256, 0), ("idgin", 512, 256)):
+    table = {"sage": (256, 0), "gin": (256, 0), "idgin": (512, 256), "gcn": (256, 0), "gat": (256, 0),
+             "idgcn": (256, 256)}
+    for kind in a.kinds.split(","):
+        d, centres = table[kind]
         try:
             run(kind, a.nodes, d, a.steps, rank, world, dev, ego_centres=centres)
         except torch.OutOfMemoryError as e:

@@ -59,8 +59,14 @@ def timeit(fn, iters=10, warm=3):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+from graphgym_amd._lib import lib
 res = {}
+res["agg_ms"] = timeit(lambda: ops._raw_spmm(g, x, 0))
 res["two_step_ms"] = timeit(lambda: two_step(g, x, W, b, True, None, 0.0))
+for u, var in ((8, 32), (4, 32), (16, 32), (8, 32)):
+    lib().mp_fused_config(u, var)
+    res[f"fused_u{u}_var{var}_ms"] = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True))
+lib().mp_fused_config(8, 0)
 res["fused_ms"] = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True))
 res["fused_saveP_ms"] = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True, want_P=True))
 ref, _ = two_step(g, x, W, b, True, None, 0.0)

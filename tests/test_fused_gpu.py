@@ -1,0 +1,176 @@
+"""The one-kernel aggregate -> transform (mp_agg_dense_f32) against the CPU oracle: SparseAdj.matmul
+(sparse_adj.py:91-97) followed by the layer's kernel product, bias and activation, forward and backward.
+fp32 within 1e-5 of the oracle (relative to the magnitude of the result); bitwise reproducible run to run."""
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, ref, tol=1e-5):
+    a, ref = a.detach().cpu().double(), ref.detach().cpu().double()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((a - ref).abs().max())
+    assert err <= tol * scale, f"max err {err:.3e} > {tol:.0e} * {scale:.3g}"
+
+
+def make_graph(n, E, seed, hubs=False, weighted=True):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, E), generator=g)
+    if hubs:   # two very long rows that share a 32-row tile, and empty rows
+        a = torch.stack([torch.full((7000,), 5), torch.randint(0, n, (7000,), generator=g)])
+        b = torch.stack([torch.full((2500,), 9), torch.randint(0, n, (2500,), generator=g)])
+        ei = torch.cat([ei, a, b], dim=1)
+        ei = ei[:, ei[0] % 13 != 4]
+    w = torch.rand(ei.size(1), generator=g) + 0.05 if weighted else None
+    return ei, w
+
+
+@pytest.mark.parametrize("n,E,F,d,weighted,hubs,self_scale", [
+    (1000, 12000, 256, 256, True, False, 0.0),
+    (37, 150, 64, 10, True, False, 0.0),
+    (2049, 30000, 128, 64, False, True, 1.25),
+    (3333, 40000, 256, 130, True, True, 0.0),
+    (64, 64, 256, 512, False, False, 2.0),
+    (33, 0 + 1, 64, 2, True, False, 0.0),
+])
+def test_agg_dense_matches_oracle(dev, n, E, F, d, weighted, hubs, self_scale):
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    ei, w = make_graph(n, E, seed=n + F, hubs=hubs, weighted=weighted)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(n, F, generator=gen)
+    W = torch.randn(F, d, generator=gen) / F ** 0.5
+    b = torch.randn(d, generator=gen)
+    adj = R.SparseAdj(ei, w, [n, n])                              # edge_index[0] = destination row
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, None if w is None else w.to(dev), dst_row=0)
+    assert ops.agg_dense_supported(G, x.to(dev), W.to(dev))
+    for relu in (False, True):
+        xr, Wr, br = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        # float64 oracle: the bar is 1e-5 on the result, and fp32 CPU sums of 7000-entry rows are themselves off
+        agg = torch.zeros(n, F, dtype=torch.float64).index_add_(
+            0, ei[0], xr.double()[ei[1]] * (w.double().unsqueeze(1) if w is not None else 1.0))
+        ref = (agg + self_scale * xr.double()) @ Wr.double() + br.double()
+        ref = torch.relu(ref) if relu else ref
+        up = torch.randn(n, d, generator=gen)
+        ref.backward(up.double())
+        xd = x.to(dev).requires_grad_(True)
+        Wd = W.to(dev).requires_grad_(True)
+        bd = b.to(dev).requires_grad_(True)
+        out = ops.agg_dense(G, xd, Wd, bias=bd, relu=relu, self_scale=self_scale)
+        out.backward(up.to(dev))
+        close(out, ref)
+        close(xd.grad, xr.grad)
+        close(Wd.grad, Wr.grad, 2e-5)
+        close(bd.grad, br.grad)
+        out2 = ops.agg_dense(G, xd, Wd, bias=bd, relu=relu, self_scale=self_scale)
+        assert torch.equal(out, out2)                             # no atomics: bitwise reproducible
+    # the fp32 oracle (SparseAdj.matmul, then the kernel product) agrees too where its own sums are short
+    if not hubs:
+        ref32 = (adj @ x + self_scale * x) @ W + b
+        close(ops.agg_dense(G, x.to(dev), W.to(dev), bias=b.to(dev), self_scale=self_scale), ref32)
+
+
+def test_agg_dense_falls_back_outside_its_shapes(dev):
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    n = 300
+    ei, w = make_graph(n, 3000, seed=3)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, w.to(dev), dst_row=0)
+    gen = torch.Generator().manual_seed(2)
+    for F, d in ((48, 32), (256, 7)):
+        x, W = torch.randn(n, F, generator=gen), torch.randn(F, d, generator=gen) / F ** 0.5
+        assert not ops.agg_dense_supported(G, x.to(dev), W.to(dev))
+        ref = (R.SparseAdj(ei, w, [n, n]) @ x) @ W
+        close(ops.agg_dense(G, x.to(dev), W.to(dev)), ref)
+    # the C entry point says so itself
+    import ctypes as C
+    from graphgym_amd._lib import lib, ptr
+    x, W, out = torch.randn(n, 48, device=dev), torch.randn(48, 32, device=dev), torch.empty(n, 32, device=dev)
+    st = lib().mp_agg_dense_f32(ptr(G.rowptr), ptr(G.col), ptr(G.val), n, 0, ptr(x), 48, 48, None, 0, 0.0, ptr(W), 32,
+                                32, None, 0, None, 0, ptr(out), 32, None)
+    assert st == 2                                                # MP_ERR_UNSUPPORTED
+
+
+def test_layers_use_the_fused_path_and_agree(dev):
+    """GCN / GIN layers at equal widths take the one-kernel path; same numbers as the explicit two-kernel order"""
+    import graphgym_amd as ga
+    from graphgym_amd import layers as L, ops
+    n, F = 500, 64
+    ei, _ = make_graph(n, 5000, seed=5, weighted=False)
+    ei = ei.to(dev)
+    x = torch.randn(n, F, generator=torch.Generator().manual_seed(4)).to(dev)
+    calls = []
+    orig = ops._raw_agg_dense
+    def spy(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+    ops._raw_agg_dense = spy
+    try:
+        torch.manual_seed(0)
+        fused = L.GCN(F, activation=torch.relu, in_features=F)
+        two = L.GCN(F, activation=torch.relu, in_features=F, order="transform_first")
+        two.load_state_dict(fused.state_dict())
+        fused, two = fused.to(dev), two.to(dev)
+        a = fused([x, ei]); nfused = len(calls)
+        b = two([x, ei])
+        assert nfused == 1 and len(calls) == 1
+        close(a, b.cpu())
+        conv = L.GINConvLayer(L._mlp2(F, F)).to(dev)
+        h = conv(x, ei)
+        assert len(calls) == 2
+        g = ga.CSRGraph.from_edge_index(ei, n)
+        ref = conv.nn(ops.spmm(g, x, "sum", self_scale=1.0))
+        close(h, ref.cpu())
+        pyg = L.GCNConvLayer(F, F).to(dev)
+        pyg(x, ei)
+        assert len(calls) == 3
+    finally:
+        ops._raw_agg_dense = orig
+
+
+@pytest.mark.parametrize("n,E,F,units,weighted,hubs", [(900, 9000, 64, 64, False, False), (2100, 30000, 256, 256, True, True),
+                                                       (70, 300, 128, 12, False, False)])
+def test_sage_concat_fused_matches_oracle(dev, n, E, F, units, weighted, hubs):
+    """[x Ws ‖ mean_j(x_j) Wn] + b -> relu (MeanGraphSage / IDSAGE.call, TfgIDLayer.py:100-117), forward and backward"""
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    ei, w = make_graph(n, E, seed=7 + n, hubs=hubs, weighted=weighted)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n, F, generator=gen)
+    Ws = torch.randn(F, units // 2, generator=gen) / F ** 0.5
+    Wn = torch.randn(F, units // 2, generator=gen) / F ** 0.5
+    b = torch.randn(units, generator=gen)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, None if w is None else w.to(dev), dst_row=0)
+    assert ops.agg_dense_supported(G, x.to(dev), Wn.to(dev))
+    for relu in (True, False):
+        xr, Wsr, Wnr, br = [t.clone().double().requires_grad_(True) for t in (x, Ws, Wn, b)]
+        msg = xr[ei[1]] * (w.double().unsqueeze(1) if w is not None else 1.0)
+        cnt = torch.zeros(n, dtype=torch.float64).index_add_(0, ei[0], torch.ones(ei.size(1), dtype=torch.float64))
+        mean = torch.zeros(n, F, dtype=torch.float64).index_add_(0, ei[0], msg) / cnt.clamp(min=1).unsqueeze(1)
+        ref = torch.cat([xr @ Wsr, mean @ Wnr], dim=1) + br
+        ref = torch.relu(ref) if relu else ref
+        up = torch.randn(n, units, generator=gen)
+        ref.backward(up.double())
+        xd, Wsd, Wnd, bd = [t.to(dev).requires_grad_(True) for t in (x, Ws, Wn, b)]
+        out = ops.sage_concat(G, xd, Wsd, Wnd, bd, relu=relu)
+        out.backward(up.to(dev))
+        close(out, ref)
+        close(xd.grad, xr.grad)
+        close(Wsd.grad, Wsr.grad, 2e-5)
+        close(Wnd.grad, Wnr.grad, 2e-5)
+        close(bd.grad, br.grad)
+    # and the layer takes this path
+    from graphgym_amd import layers as L
+    calls = []
+    orig = ops._raw_agg_dense
+    ops._raw_agg_dense = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        layer = L.MeanGraphSage(units, in_features=F).to(dev)
+        h = layer([x.to(dev), ei.to(dev)] + ([w.to(dev)] if w is not None else []))
+        assert len(calls) == 1 and h.shape == (n, units)
+    finally:
+        ops._raw_agg_dense = orig
