@@ -35,6 +35,7 @@ struct FusedArgs {
   const float* bias; int32_t act;
   float* P; int64_t ldp;
   float* out; int64_t ldo; int32_t dout;
+  int32_t out_vec4;   // out rows allow 16-byte stores
   int32_t mean;   // rows are divided by their entry count (applied to the saved P rows and in the output epilogue)
 };
 
@@ -220,16 +221,44 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
     }
     f32x2 bv = {0.f, 0.f};
     if (a.bias != nullptr && col_ok) bv = *reinterpret_cast<const f32x2*>(a.bias + cpair);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rl = (r & 3) + 8 * (r >> 2) + 4 * kk;
-      const int row = R0 + rl;
+    auto finish = [&](int r, int rl) {
       const float sc = a.mean ? inv_deg[rl] : 1.f;
       f32x2 o = {fmaf(acc0[r], sc, bv[0]), fmaf(acc1[r], sc, bv[1])};
       if (a.act == MP_ACT_RELU) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); }
-      if (col_ok && row < R1) {
-        if constexpr (NT_OUT) __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(a.out + (int64_t)row * a.ldo + cpair));
-        else *reinterpret_cast<f32x2*>(a.out + (int64_t)row * a.ldo + cpair) = o;
+      return o;
+    };
+    if (a.out_vec4) {
+      // 16-byte stores: neighbouring lanes swap one row's pair, the even lane stores row r (its two columns and
+      // the neighbour's two), the odd lane row r + 1
+      const bool odd = fr & 1;
+      const int c4 = n0 + 2 * (fr & ~1);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * kk;       // rows rl, rl + 1
+        const f32x2 m0 = finish(r, rl), m1 = finish(r + 1, rl + 1);
+        const f32x2 send = odd ? m0 : m1;
+        f32x2 recv;
+        recv[0] = __shfl_xor(send[0], 1, kWave);
+        recv[1] = __shfl_xor(send[1], 1, kWave);
+        const f32x4 o4 = odd ? f32x4{recv[0], recv[1], m1[0], m1[1]} : f32x4{m0[0], m0[1], recv[0], recv[1]};
+        const int row = R0 + rl + (odd ? 1 : 0);
+        if (row < R1) {
+          float* dst = a.out + (int64_t)row * a.ldo + c4;
+          if (c4 + 3 < a.dout) {
+            if constexpr (NT_OUT) __builtin_nontemporal_store(o4, reinterpret_cast<f32x4*>(dst));
+            else *reinterpret_cast<f32x4*>(dst) = o4;
+          } else if (c4 < a.dout) {
+            *reinterpret_cast<f32x2*>(dst) = f32x2{o4[0], o4[1]};
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const int row = R0 + rl;
+        const f32x2 o = finish(r, rl);
+        if (col_ok && row < R1) *reinterpret_cast<f32x2*>(a.out + (int64_t)row * a.ldo + cpair) = o;
       }
     }
   }
@@ -237,6 +266,7 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
 
 static int g_fused_var = 32;
 static int g_fused_u = 8;
+static int g_fused_no_vec4 = 0;
 
 template <int W, int U, int VAR>
 static int launch_fused_v(const FusedArgs& a, hipStream_t st) {
@@ -254,6 +284,7 @@ static int launch_fused(const FusedArgs& a, hipStream_t st) {
     if (g_fused_u == 16) return launch_fused_v<4, 16, 32>(a, st);
     switch (g_fused_var) {
       case 1: return launch_fused_v<4, 8, 1>(a, st);
+      case 33: return launch_fused_v<4, 8, 33>(a, st);
       case 2: return launch_fused_v<4, 8, 2>(a, st);
       case 4: return launch_fused_v<4, 8, 4>(a, st);
       case 16: return launch_fused_v<4, 8, 16>(a, st);
@@ -274,9 +305,10 @@ using namespace mp;
 extern "C" {
 
 int mp_fused_config(int rows_in_flight, int variant_bits) {
-  if ((rows_in_flight != 4 && rows_in_flight != 8 && rows_in_flight != 16) || variant_bits < 0 || variant_bits > 63) return MP_ERR_INVALID_ARG;
+  if ((rows_in_flight != 4 && rows_in_flight != 8 && rows_in_flight != 16) || variant_bits < 0 || variant_bits > 127) return MP_ERR_INVALID_ARG;
   g_fused_u = rows_in_flight;
-  g_fused_var = variant_bits;
+  g_fused_no_vec4 = (variant_bits & 64) ? 1 : 0;
+  g_fused_var = variant_bits & 63;
   return MP_OK;
 }
 
@@ -303,6 +335,7 @@ int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val
   a.rowptr = rowptr; a.col = col; a.val = val; a.N = (int32_t)N;
   a.X = X; a.ldx = ldx; a.S = S; a.lds = lds; a.self_scale = self_scale;
   a.Wm = W; a.ldw = ldw; a.bias = bias; a.act = act; a.P = P; a.ldp = ldp; a.out = out; a.ldo = ldo; a.dout = d_out; a.mean = reduce == MP_MEAN;
+  a.out_vec4 = !g_fused_no_vec4 && !mis(out, ldo, 16);
   switch (w) {
     case 4: return launch_fused<4>(a, as_stream(stream));
     case 2: return launch_fused<2>(a, as_stream(stream));

@@ -292,7 +292,7 @@ class _AggDense(torch.autograd.Function):
             raise ValueError(f"x has {x.size(0)} rows, the operator has {g.num_cols} columns")
         if g.num_cols != g.num_nodes and self_scale != 0.0:
             raise ValueError("the self term needs a square operator")
-        need_w = ctx.needs_input_grad[1]
+        need_w = ctx.needs_input_grad[1] and torch.is_grad_enabled()   # inference: no P rows written
         out, P = _raw_agg_dense(g, x, W.detach(), None if bias is None else bias.detach(), relu,
                                 S=x if self_scale != 0.0 else None, self_scale=self_scale, want_P=need_w)
         ctx.g, ctx.self_scale, ctx.relu, ctx.has_bias = g, self_scale, relu, bias is not None
@@ -402,8 +402,9 @@ class _SageConcatFused(torch.autograd.Function):
         out = torch.empty((x.size(0), ku + kn), dtype=torch.float32, device=x.device)
         b = None if bias is None else bias.detach()
         _dense_into(out[:, :ku], x, Ws.detach(), None if b is None else b[:ku], relu)
-        _, P = _raw_agg_dense(g, x, Wn.detach(), None if b is None else b[ku:], relu, want_P=ctx.needs_input_grad[2],
-                              reduce=_lib.MEAN, out=out[:, ku:])
+        _, P = _raw_agg_dense(g, x, Wn.detach(), None if b is None else b[ku:], relu,
+                              want_P=ctx.needs_input_grad[2] and torch.is_grad_enabled(), reduce=_lib.MEAN,
+                              out=out[:, ku:])
         ctx.g, ctx.relu, ctx.ku, ctx.has_bias = g, relu, ku, bias is not None
         ctx.save_for_backward(x, P, Ws, Wn, out if relu else None)
         return out

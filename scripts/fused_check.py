@@ -63,7 +63,7 @@ from graphgym_amd._lib import lib
 res = {}
 res["agg_ms"] = timeit(lambda: ops._raw_spmm(g, x, 0))
 res["two_step_ms"] = timeit(lambda: two_step(g, x, W, b, True, None, 0.0))
-for u, var in ((8, 32), (4, 32), (16, 32), (8, 32)):
+for u, var in ((8, 32), (8, 96), (8, 33), (8, 32), (8, 96)):
     lib().mp_fused_config(u, var)
     res[f"fused_u{u}_var{var}_ms"] = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True))
 lib().mp_fused_config(8, 0)
