@@ -286,13 +286,13 @@ class _AggDense(torch.autograd.Function):
     """out = act((A x + self_scale * x) W + bias) as one kernel; the backward pass runs the same kernel on the
     transposed operator: dx = (A' g + self_scale * g) W', dW = P' g with P kept by the forward launch."""
     @staticmethod
-    def forward(ctx, x, W, bias, g, self_scale, relu):
+    def forward(ctx, x, W, bias, g, self_scale, relu, grad_mode):
         x = _f32c(x, "x")
         if x.size(0) != g.num_cols:
             raise ValueError(f"x has {x.size(0)} rows, the operator has {g.num_cols} columns")
         if g.num_cols != g.num_nodes and self_scale != 0.0:
             raise ValueError("the self term needs a square operator")
-        need_w = ctx.needs_input_grad[1] and torch.is_grad_enabled()   # inference: no P rows written
+        need_w = ctx.needs_input_grad[1] and grad_mode   # inference (no_grad): no P rows written
         out, P = _raw_agg_dense(g, x, W.detach(), None if bias is None else bias.detach(), relu,
                                 S=x if self_scale != 0.0 else None, self_scale=self_scale, want_P=need_w)
         ctx.g, ctx.self_scale, ctx.relu, ctx.has_bias = g, self_scale, relu, bias is not None
@@ -323,7 +323,7 @@ class _AggDense(torch.autograd.Function):
                 dx = _raw_dense_fused(T, Wt, None, None, None, False)
                 if dx is None:
                     dx = T @ Wt
-        return dx, dW, db, None, None, None
+        return dx, dW, db, None, None, None, None
 
 
 def agg_dense(g, x, W, bias=None, relu=False, self_scale=0.0):
@@ -331,7 +331,8 @@ def agg_dense(g, x, W, bias=None, relu=False, self_scale=0.0):
     that follows it in ONE kernel (mp_agg_dense_f32) when the shapes allow (agg_dense_supported), otherwise
     the aggregation kernel followed by the fused transform"""
     if agg_dense_supported(g, x, W) and x.dtype == torch.float32:
-        return _AggDense.apply(x, W, bias, g, float(self_scale), bool(relu))
+        # grad mode is read here: inside Function.forward it is always off
+        return _AggDense.apply(x, W, bias, g, float(self_scale), bool(relu), torch.is_grad_enabled())
     return dense_fused(spmm(g, x, "sum", self_scale=self_scale), W, bias=bias, relu=relu)
 
 
@@ -396,14 +397,14 @@ class _SageConcatFused(torch.autograd.Function):
     neighbour half is the one-kernel aggregate -> transform writing into the same buffer; the backward pass
     runs the aggregate -> transform kernel on the transposed mean operator."""
     @staticmethod
-    def forward(ctx, x, Ws, Wn, bias, g, relu):
+    def forward(ctx, x, Ws, Wn, bias, g, relu, grad_mode):
         x = _f32c(x, "x")
         ku, kn = Ws.size(1), Wn.size(1)
         out = torch.empty((x.size(0), ku + kn), dtype=torch.float32, device=x.device)
         b = None if bias is None else bias.detach()
         _dense_into(out[:, :ku], x, Ws.detach(), None if b is None else b[:ku], relu)
         _, P = _raw_agg_dense(g, x, Wn.detach(), None if b is None else b[ku:], relu,
-                              want_P=ctx.needs_input_grad[2] and torch.is_grad_enabled(), reduce=_lib.MEAN,
+                              want_P=ctx.needs_input_grad[2] and grad_mode, reduce=_lib.MEAN,
                               out=out[:, ku:])
         ctx.g, ctx.relu, ctx.ku, ctx.has_bias = g, relu, ku, bias is not None
         ctx.save_for_backward(x, P, Ws, Wn, out if relu else None)
@@ -437,7 +438,7 @@ class _SageConcatFused(torch.autograd.Function):
                 T, _ = _raw_spmm(gt, gn.contiguous(), _lib.SUM)
                 dn = T @ Wnt
             dx.add_(dn)
-        return dx, dWs, dWn, db, None, None
+        return dx, dWs, dWn, db, None, None, None
 
 
 def sage_concat(g, x, Ws, Wn, bias=None, relu=False):
@@ -445,7 +446,7 @@ def sage_concat(g, x, Ws, Wn, bias=None, relu=False):
     the shapes allow, else the aggregation kernel + concat_dense"""
     if (agg_dense_supported(g, x, Wn) and x.dtype == torch.float32 and Ws.size(1) % 2 == 0
             and g.num_cols == g.num_nodes):
-        return _SageConcatFused.apply(x, Ws, Wn, bias, g, bool(relu))
+        return _SageConcatFused.apply(x, Ws, Wn, bias, g, bool(relu), torch.is_grad_enabled())
     return concat_dense(x, spmm(g, x, "mean"), Ws, Wn, bias, relu=relu)
 
 

@@ -174,3 +174,28 @@ def test_sage_concat_fused_matches_oracle(dev, n, E, F, units, weighted, hubs):
         assert len(calls) == 1 and h.shape == (n, units)
     finally:
         ops._raw_agg_dense = orig
+
+
+def test_inference_does_not_keep_the_aggregated_rows(dev):
+    """under no_grad the kernel is asked for `out` only (no [N, F] write); with grad enabled P is kept for dW"""
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    n, F = 400, 64
+    ei, _ = make_graph(n, 4000, seed=9, weighted=False)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, dst_row=0)
+    x = torch.randn(n, F).to(dev)
+    W = torch.randn(F, F).to(dev).requires_grad_(True)
+    seen = []
+    orig = ops._raw_agg_dense
+    def spy(*a, **k):
+        seen.append(bool(k.get("want_P")))
+        return orig(*a, **k)
+    ops._raw_agg_dense = spy
+    try:
+        with torch.no_grad():
+            a = ops.agg_dense(G, x, W)
+        b = ops.agg_dense(G, x, W)
+        b.sum().backward()
+    finally:
+        ops._raw_agg_dense = orig
+    assert seen == [False, True] and torch.equal(a, b.detach()) and W.grad is not None
