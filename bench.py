@@ -176,6 +176,40 @@ def main():
     copy_gbps = _rate(lambda: _check(_mplib().mp_copy_probe_f32(_ptr(x), _ptr(y), x.numel(), _mpstream())),
                       2 * x.numel() * 4)
 
+    # the whole layer (aggregate, then the MFMA feature transform + bias + ReLU) as ONE kernel next to the
+    # two-kernel order: reported beside the metric, never part of `value`
+    layer = None
+    if world == 1 and d in ops.FUSED_WIDTHS:
+        try:
+            Wl = (torch.rand((d, d), device=dev, generator=gen) - 0.5) * (2.0 / d ** 0.5)
+            bl = torch.rand((d,), device=dev, generator=gen) - 0.5
+            y2 = torch.empty_like(y)
+
+            def _ms(fn):
+                fn()
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record()
+                for _ in range(3):
+                    fn()
+                a1.record()
+                torch.cuda.synchronize()
+                return a0.elapsed_time(a1) / 3
+
+            def two_kernels():
+                ops._raw_spmm(g, x, _lib.SUM, out=y2)
+                ops._dense_into(y, y2, Wl, bl, True)
+            t_two = _ms(two_kernels)
+            ref = y[:4096].clone()
+            t_one = _ms(lambda: ops._raw_agg_dense(g, x, Wl, bl, True, out=y))
+            err = float((y[:4096] - ref).abs().max() / ref.abs().max().clamp_min(1.0))
+            layer = {"what": "relu((A_hat X) W + b), F = d_out = %d" % d, "one_kernel_ms": t_one,
+                     "two_kernel_ms": t_two, "mfma_tflops_inside_one_kernel": 2.0 * n * d * d / (t_one * 1e-3) / 1e12,
+                     "max_rel_diff_first_4096_rows": err,
+                     "kernel": "mp::agg_dense_kernel (32-row tiles reduced into LDS, MFMA against W from L2)"}
+            del y2
+        except Exception as e:   # never let the side measurement take the metric down
+            layer = {"error": repr(e)[:200]}
+
     if rank == 0:
         balg = algorithmic_bytes(n, g.nnz, d, g.val is not None)
         achieved = balg / (launch_ms * 1e-3) / 1e9
@@ -209,6 +243,8 @@ def main():
                          "launch_ms_min_median_max": [per_step[0], per_step[len(per_step) // 2], per_step[-1]],
                          "kernel": "mp::agg_rows_kernel<4,SUM,weighted> (+ hub pieces/finalize, same launch group)"},
         }
+        if layer is not None:
+            res["layer"] = layer
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(g, x)
         print(json.dumps(res), flush=True)
