@@ -49,6 +49,8 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
   constexpr int PF = (VAR & 2) ? 6 : ((VAR & 16) ? 4 : ((VAR & 32) ? 2 : 1));
   constexpr bool SKIP_MFMA = VAR & 4;     // timing diagnostics only (results are wrong): phase A alone
   constexpr bool SKIP_GATHER = VAR & 8;   //                                              phase B alone
+  constexpr bool SPLIT = VAR & 128;       //   even workgroups run phase A only, odd ones phase B only
+  constexpr bool NO_BMEM = VAR & 256;     //   phase B without its W loads and output stores (registers only)
   constexpr int F = kWave * W;
   constexpr int LDT = F + 4;   // row stride of the tile: 16-byte aligned rows, conflict-free b128 fragment reads
   __shared__ __attribute__((aligned(16))) float T[kTileRows][LDT];
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int R0 = blockIdx.x * kTileRows;
+  const int R0 = (SPLIT ? blockIdx.x >> 1 : blockIdx.x) * kTileRows;
+  const bool role_b = SPLIT && (blockIdx.x & 1);   // wave-uniform
   const int R1 = min(R0 + kTileRows, a.N);
 
   // ---- init: T = self_scale * S rows (or zeros; rows past N stay zero) ----
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
   if (lane == 0) carry_row[wave] = cont ? first_rl : -1;
   __syncthreads();   // T initialised
 
-  if (es < ee && !SKIP_GATHER) {
+  if (es < ee && !SKIP_GATHER && !role_b) {
     const float* __restrict__ xlane = a.X + lane * W;
     int rl = first_rl;
     int rend = bcast_i(rp_v, rl + 1);
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
   // 32-column accumulator tiles interleave columns (tile t holds columns n0 + 2 n + t): one 8-byte load
   // feeds both tiles and every output row is stored as 256 contiguous bytes per half-wave.
   const int fr = lane & 31, kk = lane >> 5;
-  if constexpr (SKIP_MFMA) {
+  if (SKIP_MFMA || (SPLIT && !role_b)) {
     if (T[fr][kk] == 12345.678f) a.out[0] = 1.f;   // keep phase A alive
     return;
   }
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
 #pragma unroll
     for (int g = 0; g < F / 8; ++g) {      // fully unrolled: every slot index is a constant
       const int cur = g % (PF + 1), nxt = (g + PF) % (PF + 1);
-      if (g + PF < F / 8) {
+      if (g + PF < F / 8 && !NO_BMEM) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           bq[nxt][j] = *reinterpret_cast<const f32x2*>(wp + (int64_t)(8 * (g + PF) + j) * a.ldw);
@@ -227,6 +230,10 @@ __global__ __launch_bounds__(kBlock, 4) void agg_dense_kernel(FusedArgs a) {
       if (a.act == MP_ACT_RELU) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); }
       return o;
     };
+    if constexpr (NO_BMEM) {
+      if (acc0[0] + acc1[5] == 12345.678f) a.out[1] = 1.f;
+      continue;
+    }
     if (a.out_vec4) {
       // 16-byte stores: neighbouring lanes swap one row's pair, the even lane stores row r (its two columns and
       // the neighbour's two), the odd lane row r + 1
@@ -270,7 +277,7 @@ static int g_fused_no_vec4 = 0;
 
 template <int W, int U, int VAR>
 static int launch_fused_v(const FusedArgs& a, hipStream_t st) {
-  const dim3 grid((unsigned)ceil_div(a.N, kTileRows)), block(kBlock);
+  const dim3 grid((unsigned)ceil_div(a.N, kTileRows) * ((VAR & 128) ? 2 : 1)), block(kBlock);
   if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, U, VAR>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((agg_dense_kernel<W, false, U, VAR>), grid, block, 0, st, a);
   MP_LAUNCH_CHECK();
@@ -291,6 +298,9 @@ static int launch_fused(const FusedArgs& a, hipStream_t st) {
       case 32: return launch_fused_v<4, 8, 32>(a, st);
       case 36: return launch_fused_v<4, 8, 36>(a, st);
       case 40: return launch_fused_v<4, 8, 40>(a, st);
+      case 160: return launch_fused_v<4, 8, 160>(a, st);
+      case 416: return launch_fused_v<4, 8, 416>(a, st);
+      case 296: return launch_fused_v<4, 8, 296>(a, st);
       case 8: return launch_fused_v<4, 8, 8>(a, st);
       default: break;
     }
@@ -305,10 +315,10 @@ using namespace mp;
 extern "C" {
 
 int mp_fused_config(int rows_in_flight, int variant_bits) {
-  if ((rows_in_flight != 4 && rows_in_flight != 8 && rows_in_flight != 16) || variant_bits < 0 || variant_bits > 127) return MP_ERR_INVALID_ARG;
+  if ((rows_in_flight != 4 && rows_in_flight != 8 && rows_in_flight != 16) || variant_bits < 0 || variant_bits > 511) return MP_ERR_INVALID_ARG;
   g_fused_u = rows_in_flight;
   g_fused_no_vec4 = (variant_bits & 64) ? 1 : 0;
-  g_fused_var = variant_bits & 63;
+  g_fused_var = variant_bits & ~64;
   return MP_OK;
 }
 
