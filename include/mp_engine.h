@@ -272,8 +272,9 @@ int mp_bn_train_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t l
  * No plan, no workspace; bitwise reproducible. */
 /* tuning knobs of the kernel below (process-wide): rows in flight per wave (4 | 8), variant bits
  * (1 = non-temporal stores of out; W fragments fetched 6 / 4 / 2 K groups ahead = 2 / 16 / 32, otherwise 1;
- * 64 = 8-byte instead of 16-byte stores of out; 4 and 8 are timing diagnostics that skip the MFMA / the gather
- * phase and produce WRONG results); defaults 8, 32 */
+ * 64 = 8-byte instead of 16-byte stores of out; 4, 8, 128 and 256 are timing diagnostics — skip the MFMA phase /
+ * skip the gather phase / even workgroups gather and odd ones multiply / the MFMA phase keeps W in registers and
+ * stores nothing — and produce WRONG results); defaults 8, 32 */
 int mp_fused_config(int rows_in_flight, int variant_bits);
 int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
                      const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale, const float* W,
