@@ -125,3 +125,25 @@ def test_bench_refuses_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
+
+
+def test_order_choice_and_fused_shape_gate(monkeypatch):
+    """'auto' gathers at the narrower width and aggregates first at equal widths where the one-kernel
+    aggregate -> transform applies; the shape gate and its MP_FUSED=0 switch are host logic"""
+    import types
+    import torch
+    from graphgym_amd import layers, ops
+    assert layers._pick_order("auto", 64, 256) == "aggregate_first"
+    assert layers._pick_order("auto", 256, 64) == "transform_first"
+    assert layers._pick_order("auto", 256, 256) == "aggregate_first"      # fused kernel width
+    assert layers._pick_order("auto", 100, 100) == "transform_first"      # not a fused width
+    assert layers._pick_order("transform_first", 64, 256) == "transform_first"
+    g = types.SimpleNamespace(nnz=10)
+    x, W = torch.zeros(8, 256), torch.zeros(256, 64)
+    monkeypatch.delenv("MP_FUSED", raising=False)
+    assert ops.agg_dense_supported(g, x, W)
+    assert not ops.agg_dense_supported(g, torch.zeros(8, 96), torch.zeros(96, 64))     # width
+    assert not ops.agg_dense_supported(g, x, torch.zeros(256, 7))                       # odd d_out
+    assert not ops.agg_dense_supported(types.SimpleNamespace(nnz=0), x, W)              # empty operator
+    monkeypatch.setenv("MP_FUSED", "0")
+    assert not ops.agg_dense_supported(g, x, W)
