@@ -303,3 +303,23 @@ def ego_nets(G, radius=2, return_map=False):
         return (H, torch.arange(n), torch.tensor([orig[k] for k in range(N)]),
                 torch.tensor([ego_of[k] for k in range(N)]))
     return H, torch.arange(n)
+
+
+def compute_identity(edge_index, n, k):
+    """graphgym/contrib/transform/identity.py:7-35 restated: add_remaining_self_loops, symmetric normalisation with
+    the degree scattered on edge_index[0], DENSE adjacency, diag of its powers 1..k -> [n, k]"""
+    ei, w = R.add_remaining_self_loops(edge_index, None, 1.0, n)
+    if w is None:
+        w = torch.ones(ei.size(1))
+    row, col = ei[0], ei[1]
+    deg = torch.zeros(n).index_add_(0, row, w)
+    dis = deg.pow(-0.5)
+    dis[dis == float("inf")] = 0
+    val = dis[row] * w * dis[col]
+    adj = torch.zeros(n, n).index_put_((row, col), val, accumulate=True)     # to_dense() sums duplicates
+    diag_all = [torch.diag(adj)]
+    power = adj
+    for _ in range(1, k):
+        power = power @ adj
+        diag_all.append(torch.diag(power))
+    return torch.stack(diag_all, dim=1)

@@ -139,7 +139,47 @@ def cora_like_step(d=128, centres=128, radius=2):
          batch_nodes=int(orig.numel()), batch_edges=int(ei.size(1)), ego_build_ms=t_ego * 1e3, gpu_ms_per_step=t * 1e3)
 
 
+def identity_features(n_graphs=256, k=10):
+    """`node_identity` (ID-GNN Fast) for a whole dataset of 64-node graphs (scalefree.pkl holds 256 of them):
+    the reference runs compute_identity once per graph on the CPU (dense n x n powers)"""
+    from graphgym_amd.identity import compute_identity
+    eis, batch, off = [], [], 0
+    graphs = [nx.powerlaw_cluster_graph(64, 4, 0.3, seed=s) for s in range(n_graphs)]
+    per_graph = []
+    for gi, G in enumerate(graphs):
+        e = torch.tensor(list(G.edges()), dtype=torch.int64).t()
+        ei = torch.cat([e, e.flip(0)], dim=1)
+        per_graph.append(ei)
+        eis.append(ei + off)
+        batch.append(torch.full((64,), gi, dtype=torch.int64))
+        off += 64
+    ei, batch = torch.cat(eis, dim=1).to(dev), torch.cat(batch).to(dev)
+    t_gpu, _ = sync_time(lambda: compute_identity(ei, off, k, batch=batch))
+    t0 = time.perf_counter()
+    ref = torch.cat([RL.compute_identity(e, 64, k) for e in per_graph])
+    t_cpu = time.perf_counter() - t0
+    err = float((compute_identity(ei, off, k, batch=batch).cpu() - ref).abs().max())
+    emit(what=f"node_identity features, {n_graphs} graphs x 64 nodes, k={k}", nodes=off, edges=int(ei.size(1)),
+         gpu_ms=t_gpu * 1e3, cpu_oracle_ms=t_cpu * 1e3, speedup=t_cpu / t_gpu, max_abs_diff=err,
+         cpu_note="oracle = dense restatement of identity.py:25-35 per graph, torch CPU")
+    # one larger graph (Cora-sized): width n, blocked
+    G = nx.barabasi_albert_graph(2708, 2, seed=5)
+    e = torch.tensor(list(G.edges()), dtype=torch.int64).t()
+    ei1 = torch.cat([e, e.flip(0)], dim=1)
+    t_gpu, _ = sync_time(lambda: compute_identity(ei1.to(dev), 2708, k))
+    t0 = time.perf_counter()
+    ref = RL.compute_identity(ei1, 2708, k)
+    t_cpu = time.perf_counter() - t0
+    err = float((compute_identity(ei1.to(dev), 2708, k).cpu() - ref).abs().max())
+    emit(what=f"node_identity features, one 2708-node graph (Cora-sized), k={k}", gpu_ms=t_gpu * 1e3,
+         cpu_oracle_ms=t_cpu * 1e3, speedup=t_cpu / t_gpu, max_abs_diff=err)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "identity":
+        identity_features()
+        sys.exit(0)
+    identity_features()
     cora_like_step()
     csr_build(1_000_000)
     csr_build(10_000_000)
