@@ -187,3 +187,28 @@ def test_golden_hand_graph_values_by_hand(golden):
     # edges: 0-1, 1-2, 2-0, 2-3
     expect = np.array([x[1] + x[2], x[0] + x[2], x[0] + x[1] + x[3], x[2]], dtype=np.float32)
     np.testing.assert_allclose(out, expect, rtol=1e-6, atol=1e-6)
+
+
+def test_identity_features_oracle_known_answers():
+    """oracle restatement of compute_identity (identity.py:25-35) against numpy matrix powers and a hand case"""
+    import numpy as np
+    import torch
+    from oracle import ref_layers as RL
+    # one edge 0-1: A_hat = [[1/2, 1/2], [1/2, 1/2]], idempotent => every diagonal is 1/2
+    out = RL.compute_identity(torch.tensor([[0, 1], [1, 0]]), 2, 4)
+    assert torch.allclose(out, torch.full((2, 4), 0.5))
+    # random symmetric graph with an isolated node: diag of numpy matrix powers of D^-1/2 (A + I) D^-1/2
+    rng = np.random.default_rng(0)
+    n = 12
+    A = np.triu((rng.random((n, n)) < 0.3).astype(np.float64), 1)
+    A[:, n - 1] = 0                                                   # node n-1 isolated
+    A = A + A.T
+    src, dst = np.nonzero(A)
+    ei = torch.tensor(np.stack([src, dst]), dtype=torch.int64)
+    Ah = A + np.eye(n)
+    dis = 1.0 / np.sqrt(Ah.sum(1))
+    Ah = dis[:, None] * Ah * dis[None, :]
+    ref = np.stack([np.diag(np.linalg.matrix_power(Ah, t)) for t in range(1, 6)], axis=1)
+    out = RL.compute_identity(ei, n, 5).numpy()
+    assert np.abs(out - ref).max() < 1e-6
+    assert abs(out[n - 1, 0] - 1.0) < 1e-7                            # isolated node: only its loop
