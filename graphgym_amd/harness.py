@@ -44,7 +44,7 @@ _TF_LAYER = {
 def _keras_gin_mlp(dim_in, dim):
     # main_zd.py:181-186: Dense(d, relu) -> Dense(d) -> BatchNormalization -> relu
     # BatchNormalization + relu run as one engine op (graphgym_amd.nn.BatchNorm1d(relu=True))
-    return nn.Sequential(nn.Linear(dim_in, dim), nn.ReLU(), nn.Linear(dim, dim),
+    return nn.Sequential(mpnn.Linear(dim_in, dim), nn.ReLU(), mpnn.Linear(dim, dim),
                          mpnn.BatchNorm1d(dim, eps=1e-3, momentum=0.01, relu=True))
 
 
@@ -63,7 +63,7 @@ class TfgNodeModel(nn.Module):
             else:
                 convs.append(cls(dim_inner, activation=torch.relu, in_features=d_in))
         self.convs = nn.ModuleList(convs)
-        self.mlp = nn.Sequential(nn.Flatten(), nn.Linear(dim_inner, 256), nn.ReLU(), nn.Linear(256, num_labels))
+        self.mlp = nn.Sequential(nn.Flatten(), mpnn.Linear(dim_inner, 256), nn.ReLU(), mpnn.Linear(256, num_labels))
 
     def kernel_parameters(self):
         """the variables compute_loss_Tfg regularises: every keras variable whose name contains "kernel"

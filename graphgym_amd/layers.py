@@ -109,14 +109,15 @@ def _pick_order(mode, dim_in, dim_out):
 def _fused_mlp_head(mlp, g, x, self_scale):
     """(1 + eps) x + sum_j x_j followed by an MLP that opens with Linear [-> ReLU]: the combine step and the
     first Linear (+ ReLU) run as one kernel; returns None when the MLP has another shape"""
-    if not isinstance(mlp, nn.Sequential) or len(mlp) == 0 or type(mlp[0]) is not nn.Linear:
+    if not isinstance(mlp, nn.Sequential) or len(mlp) == 0 or not isinstance(mlp[0], nn.Linear):
         return None
     lin = mlp[0]
     if not ops.agg_dense_supported(g, x, lin.weight.t()) or x.dtype != torch.float32:
         return None
-    relu = len(mlp) > 1 and type(mlp[1]) is nn.ReLU
-    h = ops.agg_dense(g, x, lin.weight.t(), bias=lin.bias, relu=relu, self_scale=self_scale)
-    for m in list(mlp)[2 if relu else 1:]:
+    own_relu = bool(getattr(lin, "relu", False))                  # graphgym_amd.nn.Linear(relu=True)
+    next_relu = not own_relu and len(mlp) > 1 and type(mlp[1]) is nn.ReLU
+    h = ops.agg_dense(g, x, lin.weight.t(), bias=lin.bias, relu=own_relu or next_relu, self_scale=self_scale)
+    for m in list(mlp)[2 if next_relu else 1:]:
         h = m(h)
     return h
 
@@ -482,7 +483,10 @@ class GINConvLayer(GINIDConvLayer):
 
 # ---- GraphGym batch wrappers: (dim_in, dim_out, bias=False, **kwargs); forward(batch) -> batch ----
 def _mlp2(dim_in, dim_out):
-    return nn.Sequential(nn.Linear(dim_in, dim_out), nn.ReLU(), nn.Linear(dim_out, dim_out))
+    # idconv.py:432-435 / layer.py:168-170: Linear -> ReLU -> Linear (same module layout and state dict; the
+    # Linears run on the engine's transform kernel)
+    from .nn import Linear as _Lin
+    return nn.Sequential(_Lin(dim_in, dim_out), nn.ReLU(), _Lin(dim_out, dim_out))
 
 
 class _BatchLayer(nn.Module):
@@ -820,8 +824,8 @@ class GAT(IDGAT):
 # ---- GraphGym-style wrappers for the TF-family keys of config/*_tf/*.yaml:29 ----
 def _tf_gin_mlp(dim_in, dim_out):
     # main_zd.py:181-186 / 214-225: Dense(d, relu) -> Dense(d) -> BatchNorm -> relu
-    from .nn import BatchNorm1d as _BN
-    return nn.Sequential(nn.Linear(dim_in, dim_out), nn.ReLU(), nn.Linear(dim_out, dim_out),
+    from .nn import BatchNorm1d as _BN, Linear as _Lin
+    return nn.Sequential(_Lin(dim_in, dim_out), nn.ReLU(), _Lin(dim_out, dim_out),
                          _BN(dim_out, eps=1e-3, momentum=0.01, relu=True))
 
 

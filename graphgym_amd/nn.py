@@ -1,4 +1,4 @@
-"""BatchNorm1d (+ ReLU) over the node axis on the engine's kernels (csrc/bn.hip).
+"""Linear (+ ReLU) and BatchNorm1d (+ ReLU) over the node axis on the engine's kernels (csrc/gemm.hip, csrc/bn.hip).
 
 Drop-in for ``torch.nn.BatchNorm1d`` as GraphGym uses it after every conv (graphgym/models/layer.py:26-35)
 and as the keras BatchNormalization in the TF path's GIN MLPs (main_zd.py:181-186): same parameter and buffer
@@ -88,3 +88,28 @@ class BatchNorm1d(nn.BatchNorm1d):
 
     def extra_repr(self):
         return super().extra_repr() + f", relu={self.relu}"
+
+
+class Linear(nn.Linear):
+    """torch.nn.Linear (same parameters, same state dict) whose forward is the engine's transform kernel with bias
+    and an optional ReLU fused into the store — the keras Dense(d, relu) / Dense(d) of the TF path's MLPs
+    (main_zd.py:181-186,214-225) and GraphGym's Linear -> ReLU -> Linear (idconv.py:432-435).  Gradients run on
+    the engine's g W' and split-K weight-gradient kernels (ops.dense_fused)."""
+
+    def __init__(self, in_features, out_features, bias=True, relu=False):
+        super().__init__(in_features, out_features, bias=bias)
+        self.relu = bool(relu)
+
+    def forward(self, x):
+        from . import ops
+        # the engine's kernels pay off on wide outputs over many rows (scripts/linear_bench.py: forward + backward
+        # 39.8 vs 45.0 ms at 10^7 x 256 -> 256, 18.6 vs 27.8 ms at 1 -> 256; the library wins at 256 -> 10 and on
+        # small batches), so narrow heads and small inputs stay on the library
+        if (x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or self.out_features < 32
+                or x.size(0) * self.out_features < (1 << 23)):
+            y = F.linear(x, self.weight, self.bias)
+            return torch.relu(y) if self.relu else y
+        return ops.dense_fused(x, self.weight.t(), bias=self.bias, relu=self.relu)
+
+    def extra_repr(self):
+        return super().extra_repr() + (", relu=True" if self.relu else "")

@@ -50,3 +50,30 @@ def test_state_dict_interchanges_with_torch(dev):
     a, b = BatchNorm1d(16, relu=True), torch.nn.BatchNorm1d(16)
     assert set(a.state_dict()) == set(b.state_dict())
     b.load_state_dict(a.state_dict())
+
+
+def test_engine_linear_matches_torch_linear(dev):
+    """graphgym_amd.nn.Linear: same parameters / state dict as torch.nn.Linear; forward and backward against a
+    float64 evaluation on both sides of its size switch (engine kernel on wide outputs over many rows, library
+    otherwise), errors measured against the sum of absolute terms of each result"""
+    import torch
+    from graphgym_amd import nn as mpnn
+    for (M, fi, fo, relu) in [(70000, 64, 128, False), (70000, 64, 128, True), (3000, 64, 128, True), (70000, 32, 10, False)]:
+        torch.manual_seed(1)
+        ref = torch.nn.Linear(fi, fo).to(dev)
+        lin = mpnn.Linear(fi, fo, relu=relu).to(dev)
+        assert set(lin.state_dict()) == set(ref.state_dict())
+        lin.load_state_dict(ref.state_dict())
+        x = torch.randn(M, fi, device=dev, requires_grad=True)
+        up = torch.randn(M, fo, device=dev)
+        y = lin(x)
+        y.backward(up)
+        xd, Wd, bd = x.detach().double(), ref.weight.detach().double(), ref.bias.detach().double()
+        pre = xd @ Wd.t() + bd
+        g = up.double() * ((y.detach() > 0) if relu else 1.0)    # the mask the forward pass produced (pre ~ 0 can flip in f64)
+        checks = [(y, torch.relu(pre) if relu else pre, xd.abs() @ Wd.abs().t() + bd.abs()),
+                  (x.grad, g @ Wd, g.abs() @ Wd.abs()),
+                  (lin.weight.grad, g.t() @ xd, g.abs().t() @ xd.abs()),
+                  (lin.bias.grad, g.sum(0), g.abs().sum(0))]
+        for got, want, mag in checks:
+            assert float(((got.double() - want).abs() / mag.clamp_min(1e-30)).max()) < 1e-5
