@@ -167,7 +167,8 @@ template <bool VEC>
 __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __restrict__ P, int64_t ldp,
                                                                 const float* __restrict__ G, int64_t ldg,
                                                                 int64_t M, int32_t F, int32_t d, int64_t chunk,
-                                                                float* __restrict__ slabs) {
+                                                                float* __restrict__ slabs,
+                                                                float* __restrict__ bias_slabs) {
   constexpr int BT = 128;                 // output tile 128 (f) x 128 (d)
   __shared__ float Ps[2][BK][BT];
   __shared__ float Gs[2][BK][BT];
@@ -216,16 +217,31 @@ __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // the bias gradient (column sums of g) rides along: the blocks of the first f-tile see every element of their
+  // g columns once, in registers, on its way to LDS
+  const bool do_bias = bias_slabs != nullptr && f0 == 0;
+  float bs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bs[i] = 0.f;
+  auto tally = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bs[i] += rg[0][i]; bs[4 + i] += rg[1][i]; }
+  };
+
   const int fr = lane & 31, fk = lane >> 5;
   const int64_t ntiles = (me - mb + BK - 1) / BK;
   if (ntiles > 0) {
     fetch(mb);
+    if (do_bias) tally();
     stash(0);
   }
   __syncthreads();
   for (int64_t t = 0; t < ntiles; ++t) {
     const int buf = (int)(t & 1);
-    if (t + 1 < ntiles) fetch(mb + (t + 1) * BK);
+    if (t + 1 < ntiles) {
+      fetch(mb + (t + 1) * BK);
+      if (do_bias) tally();
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       const float a0 = Ps[buf][kk + fk][wm * 64 + fr];
@@ -251,6 +267,17 @@ __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __r
         const int row = f0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
         if (row < F && col < d) slab[(int64_t)row * d + col] = acc[i][j][r];
       }
+    }
+  }
+  if (do_bias) {   // 16 threads hold partial sums of the same 8 columns: add them in row order through LDS
+    *reinterpret_cast<f32x4*>(&Gs[0][l_row][l_col]) = f32x4{bs[0], bs[1], bs[2], bs[3]};
+    *reinterpret_cast<f32x4*>(&Gs[0][l_row][l_col + 4]) = f32x4{bs[4], bs[5], bs[6], bs[7]};
+    __syncthreads();
+    if (tid < BT && d0 + tid < d) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int r = 0; r < BK; ++r) sacc += Gs[0][r][tid];
+      bias_slabs[c * (int64_t)d + d0 + tid] = sacc;
     }
   }
 }
@@ -314,35 +341,42 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W, const float*
 
 int mp_dense_wgrad_ws_bytes(int64_t M, int32_t F, int32_t d, size_t* bytes_host) {
   if (!bytes_host || M < 0 || F <= 0 || d <= 0) return MP_ERR_INVALID_ARG;
-  *bytes_host = (size_t)ceil_div(M > 0 ? M : 1, wgrad_chunk(M)) * (size_t)F * d * 4;
+  *bytes_host = (size_t)ceil_div(M > 0 ? M : 1, wgrad_chunk(M)) * ((size_t)F * d + d) * 4;   // + the bias partials
   return MP_OK;
 }
 
 int mp_dense_wgrad_f32(const float* P, int64_t ldp, const float* G, int64_t ldg, int64_t M, int32_t F,
-                       int32_t d, float* dW, void* ws, size_t ws_bytes, mp_stream_t stream) {
+                       int32_t d, float* dW, float* dbias, void* ws, size_t ws_bytes, mp_stream_t stream) {
   if (M < 0 || F <= 0 || d <= 0 || !dW || (M > 0 && (!P || !G)) || ldp < F || ldg < d) return MP_ERR_INVALID_ARG;
   hipStream_t st = as_stream(stream);
   if (M == 0) {
     MP_HIP(hipMemsetAsync(dW, 0, (size_t)F * d * 4, st));
+    if (dbias) MP_HIP(hipMemsetAsync(dbias, 0, (size_t)d * 4, st));
     return MP_OK;
   }
   const bool vec = !(F % 4 || d % 4 || ldp % 4 || ldg % 4) && al16(P) && al16(G);
   const int64_t chunk = wgrad_chunk(M);
   const int64_t n_chunk = ceil_div(M, chunk);
-  const size_t need = (size_t)n_chunk * F * d * 4;
+  const size_t need = (size_t)n_chunk * ((size_t)F * d + d) * 4;
   if (!ws || ws_bytes < need) return MP_ERR_WORKSPACE;
+  float* bias_slabs = dbias ? (float*)ws + (size_t)n_chunk * F * d : nullptr;
   const int64_t tiles = ceil_div(F, 128) * ceil_div(d, 128);
   if (tiles * n_chunk >= INT32_MAX) return MP_ERR_UNSUPPORTED;
   if (vec)
     hipLaunchKernelGGL((dense_wgrad_kernel<true>), dim3((unsigned)(tiles * n_chunk)), dim3(kBlock), 0, st, P, ldp, G,
-                       ldg, M, F, d, chunk, (float*)ws);
+                       ldg, M, F, d, chunk, (float*)ws, bias_slabs);
   else
     hipLaunchKernelGGL((dense_wgrad_kernel<false>), dim3((unsigned)(tiles * n_chunk)), dim3(kBlock), 0, st, P, ldp, G,
-                       ldg, M, F, d, chunk, (float*)ws);
+                       ldg, M, F, d, chunk, (float*)ws, bias_slabs);
   MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)F * d)), dim3(kBlock), 0, st, (const float*)ws,
                      n_chunk, (int64_t)F * d, dW);
   MP_LAUNCH_CHECK();
+  if (dbias) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)d)), dim3(kBlock), 0, st,
+                       (const float*)bias_slabs, n_chunk, (int64_t)d, dbias);
+    MP_LAUNCH_CHECK();
+  }
   return MP_OK;
 }
 

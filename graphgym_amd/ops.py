@@ -223,22 +223,38 @@ def _raw_agg_dense(g, x, W, bias=None, relu=False, S=None, self_scale=0.0, want_
     return out, P
 
 
-def _raw_dense_wgrad(P, G):
-    """P^T @ G on the engine's split-K MFMA kernel (None when the shape is outside it)"""
+def _raw_dense_wgrad(P, G, want_bias=False):
+    """P^T @ G on the engine's split-K MFMA kernel (None when the shape is outside it); with want_bias the pair
+    (P^T @ G, column sums of G) — the bias gradient comes out of the same pass over G"""
     L = lib()
     M, F = P.shape
     d = G.size(1)
     out = torch.empty((F, d), dtype=torch.float32, device=P.device)
+    db = torch.empty(d, dtype=torch.float32, device=P.device) if want_bias else None
     with torch.cuda.device(P.device):
         nb = C.c_size_t(0)
         check(L.mp_dense_wgrad_ws_bytes(M, F, d, C.byref(nb)))
         ws = torch.empty(max(nb.value, 1), dtype=torch.uint8, device=P.device)
-        st = L.mp_dense_wgrad_f32(ptr(P), P.stride(0), ptr(G), G.stride(0), M, F, d, ptr(out), ptr(ws), nb.value,
-                                  _stream())
+        st = L.mp_dense_wgrad_f32(ptr(P), P.stride(0), ptr(G), G.stride(0), M, F, d, ptr(out), ptr(db), ptr(ws),
+                                  nb.value, _stream())
     if st in (2, 5):
-        return None
+        return (None, None) if want_bias else None
     check(st, "mp_dense_wgrad_f32")
-    return out
+    return (out, db) if want_bias else out
+
+
+def _wgrad_and_bias(X, g, need_w, need_b):
+    """(X^T g, sum_m g[m]) for a transform's backward pass: one kernel when both are wanted"""
+    if need_w and need_b:
+        dW, db = _raw_dense_wgrad(X, g, want_bias=True)
+        if dW is not None:
+            return dW, db
+    dW = None
+    if need_w:
+        dW = _raw_dense_wgrad(X, g)
+        if dW is None:
+            dW = X.t() @ g
+    return dW, (g.sum(0) if need_b else None)
 
 
 class _DenseFused(torch.autograd.Function):
@@ -275,10 +291,9 @@ class _DenseFused(torch.autograd.Function):
             r = _raw_dense_wgrad(Xm, g)
             return r if r is not None else Xm.t() @ g
         dP = times_wt(W) if ctx.needs_input_grad[0] else None
-        dW = wgrad(P) if ctx.needs_input_grad[1] else None
+        dW, db = _wgrad_and_bias(P, g, ctx.needs_input_grad[1], ctx.has_bias)
         dQ = times_wt(W_id) if (Q is not None and ctx.needs_input_grad[2]) else None
         dWid = wgrad(Q) if (Q is not None and ctx.needs_input_grad[3]) else None
-        db = g.sum(0) if ctx.has_bias else None
         return dP, dW, dQ, dWid, db, None
 
 
@@ -305,12 +320,7 @@ class _AggDense(torch.autograd.Function):
         gm = gout.contiguous()
         if ctx.relu:
             gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
-        db = gm.sum(0) if ctx.has_bias else None
-        dW = None
-        if ctx.needs_input_grad[1]:
-            dW = _raw_dense_wgrad(P, gm)
-            if dW is None:
-                dW = P.t() @ gm
+        dW, db = _wgrad_and_bias(P, gm, ctx.needs_input_grad[1], ctx.has_bias)
         dx = None
         if ctx.needs_input_grad[0]:
             gt = ctx.g.transpose()
@@ -382,9 +392,9 @@ class _ConcatDense(torch.autograd.Function):
             return r if r is not None else Xm.t() @ gv
         dx = times_wt(gs, Ws) if ctx.needs_input_grad[0] else None
         dm = times_wt(gn, Wn) if ctx.needs_input_grad[1] else None
-        dWs = wgrad(x, gs) if ctx.needs_input_grad[2] else None
-        dWn = wgrad(m, gn) if ctx.needs_input_grad[3] else None
-        db = g.sum(0) if ctx.has_bias else None
+        dWs, dbs = _wgrad_and_bias(x, gs, ctx.needs_input_grad[2], ctx.has_bias)
+        dWn, dbn = _wgrad_and_bias(m, gn, ctx.needs_input_grad[3], ctx.has_bias)
+        db = torch.cat([dbs, dbn]) if ctx.has_bias else None
         return dx, dm, dWs, dWn, db, None
 
 
@@ -422,9 +432,9 @@ class _SageConcatFused(torch.autograd.Function):
         def wgrad(Xm, gv):
             r = _raw_dense_wgrad(Xm, gv)
             return r if r is not None else Xm.t() @ gv
-        dWs = wgrad(x, gs) if ctx.needs_input_grad[1] else None
-        dWn = wgrad(P, gn) if ctx.needs_input_grad[2] else None
-        db = gm.sum(0) if ctx.has_bias else None
+        dWs, dbs = _wgrad_and_bias(x, gs, ctx.needs_input_grad[1], ctx.has_bias)
+        dWn, dbn = _wgrad_and_bias(P, gn, ctx.needs_input_grad[2], ctx.has_bias)
+        db = torch.cat([dbs, dbn]) if ctx.has_bias else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _raw_dense_fused(gs, Ws.detach().t().contiguous(), None, None, None, False)

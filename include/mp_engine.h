@@ -301,10 +301,11 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W,
 
 /* weight gradient of the transform: dW [F, d] = P^T @ G with P [M, F], G [M, d] (backward of K11 under
  * loss.backward(), graphgym/train.py:24).  Split over the node axis into slabs in `ws`
- * (mp_dense_wgrad_ws_bytes), summed in a fixed order: bitwise reproducible.  Any F, d. */
+ * (mp_dense_wgrad_ws_bytes), summed in a fixed order: bitwise reproducible.  Any F, d.
+ * dbias (optional, [d]) receives the bias gradient sum_m G[m, :] from the same pass over G. */
 int mp_dense_wgrad_ws_bytes(int64_t M, int32_t F, int32_t d, size_t* bytes_host);
 int mp_dense_wgrad_f32(const float* P, int64_t ldp, const float* G, int64_t ldg, int64_t M,
-                       int32_t F, int32_t d, float* dW, void* ws, size_t ws_bytes,
+                       int32_t F, int32_t d, float* dW, float* dbias, void* ws, size_t ws_bytes,
                        mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
