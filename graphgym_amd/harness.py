@@ -44,7 +44,9 @@ _TF_LAYER = {
 def _keras_gin_mlp(dim_in, dim):
     # main_zd.py:181-186: Dense(d, relu) -> Dense(d) -> BatchNormalization -> relu
     # BatchNormalization + relu run as one engine op (graphgym_amd.nn.BatchNorm1d(relu=True))
-    return nn.Sequential(mpnn.Linear(dim_in, dim), nn.ReLU(), mpnn.Linear(dim, dim),
+    # Dense(d, relu): the ReLU rides in the transform kernel's store; nn.Identity keeps the module indices (and so the
+    # state-dict keys) of Linear -> ReLU -> Linear -> BatchNorm
+    return nn.Sequential(mpnn.Linear(dim_in, dim, relu=True), nn.Identity(), mpnn.Linear(dim, dim),
                          mpnn.BatchNorm1d(dim, eps=1e-3, momentum=0.01, relu=True))
 
 
@@ -63,7 +65,8 @@ class TfgNodeModel(nn.Module):
             else:
                 convs.append(cls(dim_inner, activation=torch.relu, in_features=d_in))
         self.convs = nn.ModuleList(convs)
-        self.mlp = nn.Sequential(nn.Flatten(), mpnn.Linear(dim_inner, 256), nn.ReLU(), mpnn.Linear(256, num_labels))
+        self.mlp = nn.Sequential(nn.Flatten(), mpnn.Linear(dim_inner, 256, relu=True), nn.Identity(),
+                                 mpnn.Linear(256, num_labels))
 
     def kernel_parameters(self):
         """the variables compute_loss_Tfg regularises: every keras variable whose name contains "kernel"
