@@ -199,3 +199,39 @@ def test_inference_does_not_keep_the_aggregated_rows(dev):
     finally:
         ops._raw_agg_dense = orig
     assert seen == [False, True] and torch.equal(a, b.detach()) and W.grad is not None
+
+
+def test_full_size_properties_c2(dev):
+    """C2 size (10^6 nodes, 1.1*10^7 stored entries, F = d_out = 256), where the oracle would take minutes:
+    size-independent properties — agreement with the two-kernel order (aggregation kernel, then transform
+    kernel, each checked against the oracle elsewhere), linearity in X, and the transposed-operator identity
+    <y, (A x) W> = <(A' (y W')), x> that the backward pass relies on"""
+    import graphgym_amd as ga
+    from graphgym_amd import graphgen, ops
+    n, F = 1_000_000, 256
+    ei = graphgen.ba_edge_index(n, 5, 12345, device=dev)
+    g = ga.CSRGraph.from_edge_index(ei, n, add_self_loops=True).gcn_norm()
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x1 = torch.rand((n, F), device=dev, generator=gen) * 2 - 1
+    x2 = torch.rand((n, F), device=dev, generator=gen) * 2 - 1
+    W = (torch.rand((F, F), device=dev, generator=gen) - 0.5) * (2.0 / F ** 0.5)
+    b = torch.rand((F,), device=dev, generator=gen) - 0.5
+    one, P = ops._raw_agg_dense(g, x1, W, b, True, want_P=True)
+    agg, _ = ops._raw_spmm(g, x1, 0)
+    two = ops._raw_dense_fused(agg, W, None, None, b, True)
+    scale = float(two.abs().max())
+    assert float((one - two).abs().max()) <= 1e-5 * max(1.0, scale)
+    assert float((P - agg).abs().max()) <= 1e-5 * max(1.0, float(agg.abs().max()))
+    # linearity (no bias, no activation)
+    y1, _ = ops._raw_agg_dense(g, x1, W)
+    y2, _ = ops._raw_agg_dense(g, x2, W)
+    y12, _ = ops._raw_agg_dense(g, x1 + x2, W)
+    assert float((y12 - (y1 + y2)).abs().max()) <= 1e-5 * max(1.0, float(y12.abs().max()))
+    # adjoint identity with the transposed operator (what dX = (A' g) W' computes)
+    up = torch.rand((n, F), device=dev, generator=gen) - 0.5
+    gt = g.transpose()
+    back, _ = ops._raw_agg_dense(gt, up, W.t().contiguous())
+    lhs = float((up.double() * y1.double()).sum())
+    rhs = float((back.double() * x1.double()).sum())
+    mag = float((up.double() * y1.double()).abs().sum())          # the sums cancel: compare against sum |terms|
+    assert abs(lhs - rhs) <= 1e-6 * mag, (lhs, rhs, mag)
