@@ -387,9 +387,6 @@ class _ConcatDense(torch.autograd.Function):
             r = _raw_dense_fused(gv, Wm.detach().t().contiguous(), None, None, None, False)
             return r if r is not None else gv @ Wm.t()
 
-        def wgrad(Xm, gv):
-            r = _raw_dense_wgrad(Xm, gv)
-            return r if r is not None else Xm.t() @ gv
         dx = times_wt(gs, Ws) if ctx.needs_input_grad[0] else None
         dm = times_wt(gn, Wn) if ctx.needs_input_grad[1] else None
         dWs, dbs = _wgrad_and_bias(x, gs, ctx.needs_input_grad[2], ctx.has_bias)
@@ -429,9 +426,6 @@ class _SageConcatFused(torch.autograd.Function):
             gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
         gs, gn = gm[:, :ku], gm[:, ku:]
 
-        def wgrad(Xm, gv):
-            r = _raw_dense_wgrad(Xm, gv)
-            return r if r is not None else Xm.t() @ gv
         dWs, dbs = _wgrad_and_bias(x, gs, ctx.needs_input_grad[1], ctx.has_bias)
         dWn, dbn = _wgrad_and_bias(P, gn, ctx.needs_input_grad[2], ctx.has_bias)
         db = torch.cat([dbs, dbn]) if ctx.has_bias else None
