@@ -216,6 +216,15 @@ class CSRGraph:
             self._deg_cnt = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
         return self._deg_cnt
 
+    def max_row_entries(self):
+        """the longest row (one device reduction + one host read, cached): the one-kernel aggregate -> transform
+        gives a row to the four waves of one workgroup, so extreme hubs are sent to the plan-based kernel"""
+        cached = self.__dict__.get("_max_row")
+        if cached is None:
+            cached = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if self.num_nodes > 0 else 0
+            self.__dict__["_max_row"] = cached
+        return cached
+
     def transpose_mean(self):
         """A^T with entry (j <- i) = val / count(i): the backward operator of reduce='mean'"""
         if self._t_mean is None:

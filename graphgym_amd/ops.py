@@ -192,6 +192,7 @@ def _raw_dense_fused(P, W, Q, W_id, bias, relu):
 
 
 FUSED_WIDTHS = (64, 128, 256)
+FUSED_MAX_ROW = 1 << 18      # longer rows (star-like hubs) go to the plan-based kernel, which spreads them over many waves
 
 
 def agg_dense_supported(g, x, W):
@@ -200,7 +201,7 @@ def agg_dense_supported(g, x, W):
     if os.environ.get("MP_FUSED", "1") == "0":
         return False
     return (x.size(1) in FUSED_WIDTHS and W.size(1) % 2 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
-            and g.nnz > 0)
+            and g.nnz > 0 and g.max_row_entries() <= FUSED_MAX_ROW)
 
 
 def _raw_agg_dense(g, x, W, bias=None, relu=False, S=None, self_scale=0.0, want_P=False, reduce=_lib.SUM,

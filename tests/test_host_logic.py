@@ -138,12 +138,13 @@ def test_order_choice_and_fused_shape_gate(monkeypatch):
     assert layers._pick_order("auto", 256, 256) == "aggregate_first"      # fused kernel width
     assert layers._pick_order("auto", 100, 100) == "transform_first"      # not a fused width
     assert layers._pick_order("transform_first", 64, 256) == "transform_first"
-    g = types.SimpleNamespace(nnz=10)
+    g = types.SimpleNamespace(nnz=10, max_row_entries=lambda: 5)
     x, W = torch.zeros(8, 256), torch.zeros(256, 64)
     monkeypatch.delenv("MP_FUSED", raising=False)
     assert ops.agg_dense_supported(g, x, W)
     assert not ops.agg_dense_supported(g, torch.zeros(8, 96), torch.zeros(96, 64))     # width
     assert not ops.agg_dense_supported(g, x, torch.zeros(256, 7))                       # odd d_out
-    assert not ops.agg_dense_supported(types.SimpleNamespace(nnz=0), x, W)              # empty operator
+    assert not ops.agg_dense_supported(types.SimpleNamespace(nnz=0, max_row_entries=lambda: 0), x, W)   # empty operator
+    assert not ops.agg_dense_supported(types.SimpleNamespace(nnz=10, max_row_entries=lambda: 1 << 20), x, W)   # star-like hub
     monkeypatch.setenv("MP_FUSED", "0")
     assert not ops.agg_dense_supported(g, x, W)
