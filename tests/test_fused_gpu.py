@@ -235,3 +235,25 @@ def test_full_size_properties_c2(dev):
     rhs = float((back.double() * x1.double()).sum())
     mag = float((up.double() * y1.double()).abs().sum())          # the sums cancel: compare against sum |terms|
     assert abs(lhs - rhs) <= 1e-6 * mag, (lhs, rhs, mag)
+
+
+def test_star_hub_goes_to_the_plan_based_kernel(dev):
+    """a row longer than FUSED_MAX_ROW (a star's centre) is not given to one workgroup: agg_dense falls back to the
+    aggregation kernel (hub rows cut into pieces over many waves) + transform kernel, same numbers"""
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    leaves, F = ops.FUSED_MAX_ROW + 5000, 64
+    n = leaves + 1
+    ei = torch.stack([torch.zeros(leaves, dtype=torch.int64), torch.arange(1, n)])      # row 0 <- every leaf
+    ei = torch.cat([ei, ei.flip(0)], dim=1)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, dst_row=0)
+    assert G.max_row_entries() == leaves
+    gen = torch.Generator().manual_seed(0)
+    x, W = torch.randn(n, F, generator=gen), torch.randn(F, F, generator=gen) / 8
+    assert not ops.agg_dense_supported(G, x.to(dev), W.to(dev))
+    out = ops.agg_dense(G, x.to(dev), W.to(dev))
+    ref_centre = x[1:].double().sum(0) @ W.double()
+    ref_leaf = x[0].double() @ W.double()
+    close(out[0], ref_centre.float(), 2e-5)
+    close(out[1], ref_leaf.float())
+    close(out[n - 1], ref_leaf.float())
