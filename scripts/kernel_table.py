@@ -1,0 +1,114 @@
+"""Every kernel family of the path at the C4 shape (N = 10^7, 1.1*10^8 stored entries, d = 256) against its roofline:
+algorithmic bytes (or flops) per launch / measured time.  Prints JSON lines and a markdown table."""
+import sys, os, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import graphgym_amd as ga
+from graphgym_amd import graphgen, ops, nn as mpnn
+from graphgym_amd.graph import CSRGraph
+dev = torch.device("cuda:0")
+n, d = int(os.environ.get("NODES", "10000000")), 256
+HBM, MFMA = 8000.0, 157.3
+ei = graphgen.ba_edge_index(n, 5, 12345, device=dev)
+E_in = ei.size(1)
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+rows = []
+def rec(name, ms, gbytes=None, tflop=None, note=""):
+    r = {"kernel": name, "ms": round(ms, 3)}
+    if gbytes is not None:
+        r["algorithmic_GB"] = round(gbytes, 2); r["GBps"] = round(gbytes / ms * 1e3, 0); r["frac_hbm_8TBps"] = round(gbytes / ms * 1e3 / HBM, 3)
+    if tflop is not None:
+        r["TFLOP"] = round(tflop, 3); r["TFLOPps"] = round(tflop / ms * 1e3, 1); r["frac_f32_mfma_157TF"] = round(tflop / ms * 1e3 / MFMA, 3)
+    r["note"] = note
+    rows.append(r); print(json.dumps(r), flush=True)
+
+# build pipeline (sort-bound)
+def build():
+    return CSRGraph.from_edge_index(ei, n, add_self_loops=True)
+t = timeit(build, iters=3, warm=1)
+rec("csr_from_coo (keys, radix sort, rowptr, emit) + self loops", t, (E_in + n) * 24 * 2 / 1e9, note="~2 sort passes x 24 B per key (estimate); sort-bound")
+g0 = build()
+nnz = g0.nnz
+t = timeit(lambda: g0.degree("row"))
+rec("degree_row (weighted row sums)", t, (nnz * 4 + n * 8) / 1e9)
+g = g0.gcn_norm()
+t = timeit(lambda: g0.gcn_norm())
+rec("gcn_norm = degree + inv_sqrt + norm_edges", t, (nnz * 4 + n * 8 + nnz * 16 + n * 8) / 1e9, note="dinv[col] is a random 4-byte gather per entry")
+def tr():
+    g._t = None
+    return g.transpose()
+t_tr = timeit(tr, iters=3, warm=1)
+gt = g.transpose()
+rec("csr_transpose (keys, radix sort, emit; once per graph)", t_tr, nnz * 24 * 2 / 1e9, note="pattern shared with the un-normalised graph: values permuted only")
+def pl():
+    g._plan = None
+    return g.plan()
+rec("plan build (segments + hubs; once per graph)", timeit(pl, iters=3, warm=1), note="cached with the pattern (first build: ~50 us of kernels + one host read)")
+del g0
+
+x = torch.rand(n, d, device=dev) * 2 - 1
+y = torch.empty(n, d, device=dev)
+agg_bytes = (nnz * (d * 4 + 8) + n * (d * 4 + 4)) / 1e9
+for red, name in ((0, "sum"), (1, "mean"), (2, "max")):
+    t = timeit(lambda: ops._raw_spmm(g, x, red, out=y, want_argmax=False))
+    rec(f"agg_rows {name} (weighted)", t, agg_bytes)
+t = timeit(lambda: ops._raw_spmm(gt, x, 0, out=y))
+rec("agg_rows sum on the transposed operator (backward)", t, agg_bytes)
+t = timeit(lambda: ops._raw_spmm(g, x, 0, S=x, self_scale=1.0, out=y))
+rec("agg_rows sum + self term (GIN combine)", t, agg_bytes + n * d * 4 / 1e9)
+ids = torch.arange(0, n, 100, device=dev)
+col_m = g.mark_ids(ids)
+q = torch.empty(n, d, device=dev)
+def two_branch():
+    ops.idgnn_aggregate(g, ids, x, col_marked=col_m)
+t = timeit(two_branch)
+rec("agg_rows two-branch (P and Q in one pass, 1 % identity nodes)", t, agg_bytes + n * d * 4 / 1e9)
+del q
+# attention pieces
+s = None
+t = timeit(lambda: ops._raw_sddmm_dot(g, x, x, 1, 1.0))
+rec("sddmm_stream (dot-product scores, 1 head)", t, (nnz * (d * 4 + 12) + n * d * 4) / 1e9, note="K[col] row per entry, Q[row] once per row")
+sc = ops._raw_sddmm_dot(g, x, x, 1, 1.0 / 16)
+t = timeit(lambda: ops.edge_softmax(g, sc))
+rec("row_softmax (per destination row)", t, (nnz * 8 + n * 4) / 1e9, note="16 lanes per row, 3 passes over the row's scores (L2-resident)")
+del sc
+# dense transform kernels
+W = torch.randn(d, d, device=dev) * 0.05
+b = torch.randn(d, device=dev)
+t = timeit(lambda: ops._dense_into(y, x, W, b, True))
+rec("dense_fused (P W + b, ReLU)", t, tflop=2.0 * n * d * d / 1e12)
+t = timeit(lambda: ops._raw_dense_wgrad(x, y, want_bias=True))
+rec("dense_wgrad (+ bias gradient)", t, tflop=2.0 * n * d * d / 1e12)
+t = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True, out=y))
+rec("agg_dense (aggregate -> transform, one kernel)", t, agg_bytes, tflop=2.0 * n * d * d / 1e12, note="moves the aggregation's bytes AND does the transform's flops")
+# batch norm
+bn = mpnn.BatchNorm1d(d, relu=True).to(dev)
+xr = x.clone().requires_grad_(True)
+t_f = timeit(lambda: bn(x))
+rec("batchnorm + ReLU forward (statistics pass + apply pass)", t_f, 3 * n * d * 4 / 1e9)
+out = bn(xr); up = torch.rand_like(out)
+def bwd():
+    o = bn(xr); o.backward(up); xr.grad = None
+t_fb = timeit(bwd)
+rec("batchnorm + ReLU backward (two passes)", t_fb - t_f, 7 * n * d * 4 / 1e9, note="time = (forward + backward) - forward")
+del out, up, xr
+# identity rows
+u = torch.rand(ids.numel(), d, device=dev)
+t = timeit(lambda: ops.gather_rows(x, ids))
+rec("rows_gather (identity rows)", t, 2 * ids.numel() * d * 4 / 1e9, note="10^5 rows: launch / latency-bound")
+print("\n| kernel | ms | algorithmic GB | GB/s | % of 8 TB/s | TFLOP/s | % of 157 TF | note |\n|---|---|---|---|---|---|---|---|")
+for r in rows:
+    print(f"| {r['kernel']} | {r['ms']} | {r.get('algorithmic_GB', '')} | {r.get('GBps', '')} | "
+          f"{'' if 'frac_hbm_8TBps' not in r else round(100 * r['frac_hbm_8TBps'], 1)} | {r.get('TFLOPps', '')} | "
+          f"{'' if 'frac_f32_mfma_157TF' not in r else round(100 * r['frac_f32_mfma_157TF'], 1)} | {r['note']} |")
