@@ -257,3 +257,29 @@ def test_star_hub_goes_to_the_plan_based_kernel(dev):
     close(out[0], ref_centre.float(), 2e-5)
     close(out[1], ref_leaf.float())
     close(out[n - 1], ref_leaf.float())
+
+
+def test_tuning_variants_are_numerically_identical(dev):
+    """mp_fused_config knobs (rows in flight, W prefetch depth, store width / non-temporal stores) change the
+    schedule, not the arithmetic: bitwise the same output as the default configuration"""
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    from graphgym_amd._lib import lib
+    n, F = 4000, 256
+    ei, w = make_graph(n, 60000, seed=21, hubs=True)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, w.to(dev), dst_row=0)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, F, generator=gen).to(dev)
+    W = (torch.randn(F, F, generator=gen) / 16).to(dev)
+    b = torch.randn(F, generator=gen).to(dev)
+    L = lib()
+    try:
+        assert L.mp_fused_config(8, 32) == 0
+        base, _ = ops._raw_agg_dense(G, x, W, b, True)
+        for u, var in ((8, 0), (8, 1), (8, 16), (8, 2), (8, 33), (8, 96), (4, 32), (16, 32)):
+            assert L.mp_fused_config(u, var) == 0
+            out, _ = ops._raw_agg_dense(G, x, W, b, True)
+            assert torch.equal(out, base), (u, var)
+        assert L.mp_fused_config(3, 0) == 1 and L.mp_fused_config(8, 4096) == 1      # MP_ERR_INVALID_ARG
+    finally:
+        L.mp_fused_config(8, 32)
