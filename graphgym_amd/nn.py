@@ -93,8 +93,8 @@ class BatchNorm1d(nn.BatchNorm1d):
 class Linear(nn.Linear):
     """torch.nn.Linear (same parameters, same state dict) whose forward is the engine's transform kernel with bias
     and an optional ReLU fused into the store — the keras Dense(d, relu) / Dense(d) of the TF path's MLPs
-    (main_zd.py:181-186,214-225) and GraphGym's Linear -> ReLU -> Linear (idconv.py:432-435).  Gradients run on
-    the engine's g W' and split-K weight-gradient kernels (ops.dense_fused)."""
+    (main_zd.py:181-186,214-225) and GraphGym's Linear -> ReLU -> Linear (idconv.py:432-435).  Backward: the weight
+    and bias gradients come from the engine's split-K kernel, g W' (a plain product) from the library GEMM."""
 
     def __init__(self, in_features, out_features, bias=True, relu=False):
         super().__init__(in_features, out_features, bias=bias)
