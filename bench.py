@@ -4,16 +4,23 @@ GCN d=256 on 100M-edge scale-free").
 
     python bench.py --gpus 1 --steps 50 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--mode step]
 
-A step is one pass of the aggregation  Y = A_hat X  over one graph resident in HBM:
-A_hat = D^-1/2 (A + I) D^-1/2 of a Barabasi-Albert BA(10^7, 5) graph (about 1.1*10^8 stored
-entries incl. self loops), X [10^7, 256] fp32.  With N > 1 every rank owns its own graph of that
-size (weak scaling; independent units, no data-path collective — DESIGN.md §6).
+--mode aggregate (default): a step is one pass of the aggregation  Y = A_hat X  over one graph resident
+in HBM: A_hat = D^-1/2 (A + I) D^-1/2 of a Barabasi-Albert BA(10^7, 5) graph (about 1.1*10^8 stored
+entries incl. self loops), X [10^7, 256] fp32.  With N > 1 every rank owns its own graph of that size
+(weak scaling; independent units, no data-path collective — DESIGN.md §6).
 
-Prints ONE JSON line on rank 0.  `roofline` prices the aggregation launch against HBM;
-`cpu_baseline` times the CPU oracle (the op-for-op restatement of the reference's CPU path) on a
-bounded sample of the same workload on this box's host cores.
+--mode step: a step is one ID-GCN training step (forward, loss, backward, ONE-bucket gradient all-reduce
+over RCCL, Adam) on each rank's shard of a batch of ego nets dealt out by stored entries (LPT); the
+all-reduce is inside the timed region and also reported on its own (`allreduce_ms`).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the aggregation launch against HBM; `cpu_baseline`
+times the CPU oracle (the op-for-op restatement of the reference's CPU path) on a bounded sample of the
+same workload on this box's host cores.
+
+X and Y are allocated through the engine (graphgym_amd/placement.py): Y lands where it conflicts least
+with X — the same call the product's operators make for their outputs; there is no candidate loop here.
 """
 import argparse
 import json
@@ -27,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "aggregated edges/sec + achieved HBM GB/s, GCN d=256 on 100M-edge scale-free"
 
 
 def algorithmic_bytes(n, nnz, d, weighted):
@@ -35,11 +43,11 @@ def algorithmic_bytes(n, nnz, d, weighted):
     return nnz * d * 4 + n * d * 4 + nnz * 4 + (nnz * 4 if weighted else 0) + (n + 1) * 4
 
 
-def cpu_baseline(g, x, seconds=15.0):
-    """oracle/ref_ops.coo_aggregate_sum_chunked on the leading edge chunks of the same graph"""
+def cpu_baseline(g, x, seconds=8.0):
+    """the reference-style gather -> scale -> index_add_ (oracle/ref_ops) on the leading edge
+    chunks of the same graph at 6 threads (graphgym/config.py:57) and on all cores, plus the best-available CPU
+    line torch.sparse_csr @ X; every leg bounded to ~`seconds` of CPU work."""
     from oracle import ref_ops
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
     n, d = x.shape
     chunk = 4_000_000
     take = min(g.nnz, 25 * chunk)
@@ -47,53 +55,82 @@ def cpu_baseline(g, x, seconds=15.0):
     src = g.col[:take].long().cpu()
     w = g.val[:take].cpu() if g.val is not None else None
     xc = x.cpu()
-    out = torch.zeros((n, d), dtype=torch.float32)
-    ref_ops.coo_aggregate_sum_chunked(dst[:200_000], src[:200_000], None if w is None else w[:200_000], xc, out,
-                                      chunk)  # touch pages / warm the thread pool
-    t0 = time.perf_counter()
-    done = ref_ops.coo_aggregate_sum_chunked(dst, src, w, xc, out, chunk, max_seconds=seconds)
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"first {done} of {g.nnz} stored entries of the same graph, same X (fp32, d={d}), "
-                      f"gather*scale -> index_add_ in 4M-edge chunks, {dt:.1f} s of CPU work"}
+    cores = os.cpu_count() or 1
+    legs = []
+
+    def gather_leg(threads):
+        torch.set_num_threads(threads)
+        out = torch.zeros((n, d), dtype=torch.float32)
+        ref_ops.coo_aggregate_sum_chunked(dst[:200_000], src[:200_000], None if w is None else w[:200_000], xc, out,
+                                          chunk)  # touch pages / warm the thread pool
+        t0 = time.perf_counter()
+        done = ref_ops.coo_aggregate_sum_chunked(dst, src, w, xc, out, chunk, max_seconds=seconds)
+        dt = time.perf_counter() - t0
+        return {"what": "reference-style gather*scale -> index_add_ in 4M-edge chunks (oracle/ref_ops)",
+                "threads": threads, "edges": done, "seconds": dt, "edges_per_s": done / dt}
+
+    legs.append(gather_leg(min(6, cores)))
+    legs.append(gather_leg(cores))
+    # torch.sparse_csr @ X on the leading rows (sized from the gather leg's rate to ~`seconds`).  torch's CPU kernel
+    # indexes the dense operand with 32-bit offsets (it crashes on a [10^7, 256] operand), so the sample's columns
+    # are renumbered to the rows they actually reference and X is compacted to those rows.
+    try:
+        torch.set_num_threads(cores)
+        rp = g.rowptr.long().cpu()
+        target = int(min(take, 6_000_000, max(2_000_000, legs[-1]["edges_per_s"] * seconds * 2)))
+        r = int(torch.searchsorted(rp, torch.tensor([target]))[0])
+        r = max(1, min(r, n))
+        e = int(rp[r])
+        cols, inv = torch.unique(g.col[:e].long().cpu(), return_inverse=True)
+        xs = xc[cols]
+        assert xs.numel() < 2 ** 31
+        A = torch.sparse_csr_tensor(rp[:r + 1], inv, g.val[:e].cpu() if g.val is not None else torch.ones(e),
+                                    size=(r, cols.numel()))
+        t0 = time.perf_counter()
+        _ = A @ xs
+        dt = time.perf_counter() - t0
+        legs.append({"what": "torch.sparse_csr_tensor @ X (best-available CPU line; X compacted to the referenced rows)",
+                     "threads": cores, "edges": e, "rows": r, "x_rows": int(cols.numel()), "seconds": dt,
+                     "edges_per_s": e / dt})
+    except Exception as exc:   # never let a side leg take the metric down
+        legs.append({"what": "torch.sparse_csr_tensor @ X", "error": repr(exc)[:200]})
+    main = legs[1]
+    return {"value": main["edges_per_s"], "unit": "edges/s", "cores": main["threads"], "kind": "port",
+            "sample": f"first {main['edges']} of {g.nnz} stored entries of the same graph, same X (fp32, d={d}), "
+                      f"gather*scale -> index_add_ in 4M-edge chunks, {main['seconds']:.1f} s of CPU work",
+            "host_cores": cores, "legs": legs}
 
 
 def pmc_traffic(workload):
-    """per-launch HBM bytes from the committed rocprofv3 PMC passes (profiles/), if they match"""
+    """per-launch HBM bytes from the committed rocprofv3 PMC passes (profiles/), if they match this workload:
+    (bytes, provenance) — a stored measurement of the same command, not a value measured in this run"""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
         if rec.get("workload") == workload:
-            return rec.get("hbm_bytes_per_launch")
+            return rec.get("hbm_bytes_per_launch"), (
+                "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                f"({rec.get('source', 'see profiles/')}), committed; NOT measured in this run")
     except Exception:
         pass
-    return None
+    return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--nodes", type=int, default=10_000_000)
-    ap.add_argument("--m", type=int, default=5)
-    ap.add_argument("--d", type=int, default=256)
-    ap.add_argument("--graph", choices=["ba", "powerlaw_cluster"], default="ba",
-                    help="ba = Barabasi-Albert (default); powerlaw_cluster = Holme-Kim with triangle probability 0.3")
-    ap.add_argument("--permute", action="store_true", help="relabel nodes by a random permutation (seed 1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def _ms(fn, reps=3):
+    fn()
+    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a0.record()
+    for _ in range(reps):
+        fn()
+    a1.record()
+    torch.cuda.synchronize()
+    return a0.elapsed_time(a1) / reps
 
+
+def run_aggregate(args, rank, world, dev):
     import graphgym_amd as ga
-    from graphgym_amd import _lib, dist as D, graphgen, ops
-
-    rank, local, world = D.init_from_env()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = torch.device("cuda", torch.cuda.current_device())
+    from graphgym_amd import _lib, dist as D, graphgen, ops, placement
 
     n, d = args.nodes, args.d
     ei = graphgen.ba_edge_index(n, args.m, seed=12345 + rank, device=dev,
@@ -102,37 +139,19 @@ def main():
     g = ga.CSRGraph.from_edge_index(ei, n, add_self_loops=True).gcn_norm("row")
     del ei
     g.plan()
-    gen = torch.Generator(device=dev).manual_seed(7 + rank)
-    x = torch.rand((n, d), device=dev, generator=gen) * 2 - 1
-    # Output placement.  On MI355X the same launch runs ~12 % slower when X and Y happen to be backed by
-    # the same physical HBM region (a plain torch copy between the two tensors shows the same split —
-    # profiles/r01_placement.log); which region an allocation lands in is not under the
-    # caller's control.  So the untimed set-up allocates a few candidate output buffers, times each
-    # briefly, keeps the fastest and reports all of them.
-    # Candidates are spaced ~36 GB apart (the size of the regions observed: 288 GB / 8) with throw-away
-    # allocations, so that they cannot all share X's region.
-    cands, spacers = [], []
-    for i in range(3):
-        cands.append(torch.empty((n, d), dtype=torch.float32, device=dev))
-        if i < 2:
-            try:
-                spacers.append(torch.empty(int(26e9), dtype=torch.uint8, device=dev))
-            except torch.OutOfMemoryError:
-                pass
-    del spacers
-    cand_ms = []
-    for c in cands:
-        ops._raw_spmm(g, x, _lib.SUM, out=c)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            ops._raw_spmm(g, x, _lib.SUM, out=c)
-        e1.record()
-        torch.cuda.synchronize()
-        cand_ms.append(e0.elapsed_time(e1) / 3)
-    y = cands[min(range(len(cands)), key=lambda i: cand_ms[i])]
-    del cands, c
     torch.cuda.empty_cache()
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+    # resident feature matrix and the output, both through the engine's placement (the call ops.spmm makes)
+    x = placement.empty((n, d), torch.float32, dev)     # None below the size where placement matters
+    x_engine = x is not None
+    if x is None:
+        x = torch.empty((n, d), dtype=torch.float32, device=dev)
+    x.uniform_(-1.0, 1.0, generator=gen)
+    y = placement.empty_or_torch((n, d), dev, reads=(x,))
+    ar = placement.arena(dev, create=False)
+    place = {"engine_placed": bool(ar is not None and ar.owns(y)), "x_in_arena": bool(x_engine),
+             "predicted_conflict": getattr(y, "_mp_predicted_conflict", None),
+             "arena": None if ar is None else ar.stats()}
 
     def step():
         ops._raw_spmm(g, x, _lib.SUM, out=y)
@@ -156,25 +175,49 @@ def main():
     per_step = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
     launch_ms = sum(per_step) / args.steps
 
+    def pct(p):
+        return per_step[min(len(per_step) - 1, int(round(p * (len(per_step) - 1))))]
+
+    # cold launches: a 512 MB memset between launches flushes L2 / Infinity Cache
+    flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+    cold = []
+    for _ in range(min(10, args.steps)):
+        flush.zero_()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        step()
+        a1.record()
+        torch.cuda.synchronize()
+        cold.append(a0.elapsed_time(a1))
+    cold.sort()
+    del flush
+
     # measured streaming rates on this box: a read-only pass over X (the aggregation is 92 % reads) and a
     # copy X -> Y (50 % writes); the aggregation's algorithmic rate is quoted against both and the nominal peak
     from graphgym_amd._lib import lib as _mplib, ptr as _ptr, check as _check
     from graphgym_amd.graph import _stream as _mpstream
     sink = torch.empty(256 * 8 * 256, dtype=torch.float32, device=dev)
+    read_ms = _ms(lambda: _check(_mplib().mp_read_probe_f32(_ptr(x), x.numel(), _ptr(sink), _mpstream())))
+    copy_ms = _ms(lambda: _check(_mplib().mp_copy_probe_f32(_ptr(x), _ptr(y), x.numel(), _mpstream())))
+    read_gbps = x.numel() * 4 / (read_ms * 1e-3) / 1e9
+    copy_gbps = 2 * x.numel() * 4 / (copy_ms * 1e-3) / 1e9
 
-    def _rate(fn, nbytes):
-        fn()
-        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a0.record()
-        for _ in range(3):
-            fn()
-        a1.record()
-        torch.cuda.synchronize()
-        return nbytes / (a0.elapsed_time(a1) / 3 * 1e-3) / 1e9
-    read_gbps = _rate(lambda: _check(_mplib().mp_read_probe_f32(_ptr(x), x.numel(), _ptr(sink), _mpstream())),
-                      x.numel() * 4)
-    copy_gbps = _rate(lambda: _check(_mplib().mp_copy_probe_f32(_ptr(x), _ptr(y), x.numel(), _mpstream())),
-                      2 * x.numel() * 4)
+    balg = algorithmic_bytes(n, g.nnz, d, g.val is not None)
+
+    # backward of the aggregation = the same kernel on the transposed operator (dX = A_hat^T dY)
+    backward = None
+    if world == 1:
+        try:
+            gt = g.transpose()
+            gt.plan()
+            dx = placement.empty_or_torch((n, d), dev, reads=(y,))
+            bms = _ms(lambda: ops._raw_spmm(gt, y, _lib.SUM, out=dx), reps=5)
+            backward = {"what": "dX = A_hat^T dY on the cached transposed CSR (same kernel)", "launch_ms": bms,
+                        "edges_per_s": g.nnz / (bms * 1e-3), "hbm_gbps_algorithmic": balg / (bms * 1e-3) / 1e9,
+                        "frac": balg / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del dx, gt
+        except Exception as e:
+            backward = {"error": repr(e)[:200]}
 
     # the whole layer (aggregate, then the MFMA feature transform + bias + ReLU) as ONE kernel next to the
     # two-kernel order: reported beside the metric, never part of `value`
@@ -183,40 +226,31 @@ def main():
         try:
             Wl = (torch.rand((d, d), device=dev, generator=gen) - 0.5) * (2.0 / d ** 0.5)
             bl = torch.rand((d,), device=dev, generator=gen) - 0.5
-            y2 = torch.empty_like(y)
-
-            def _ms(fn):
-                fn()
-                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a0.record()
-                for _ in range(3):
-                    fn()
-                a1.record()
-                torch.cuda.synchronize()
-                return a0.elapsed_time(a1) / 3
+            y2 = placement.empty_or_torch((n, d), dev, reads=(x,))
+            y3 = placement.empty_or_torch((n, d), dev, reads=(y2,))
 
             def two_kernels():
                 ops._raw_spmm(g, x, _lib.SUM, out=y2)
-                ops._dense_into(y, y2, Wl, bl, True)
+                ops._dense_into(y3, y2, Wl, bl, True)
             t_two = _ms(two_kernels)
-            ref = y[:4096].clone()
+            ref = y3[:4096].clone()
             t_one = _ms(lambda: ops._raw_agg_dense(g, x, Wl, bl, True, out=y))
             err = float((y[:4096] - ref).abs().max() / ref.abs().max().clamp_min(1.0))
             layer = {"what": "relu((A_hat X) W + b), F = d_out = %d" % d, "one_kernel_ms": t_one,
                      "two_kernel_ms": t_two, "mfma_tflops_inside_one_kernel": 2.0 * n * d * d / (t_one * 1e-3) / 1e12,
                      "max_rel_diff_first_4096_rows": err,
                      "kernel": "mp::agg_dense_kernel (32-row tiles reduced into LDS, MFMA against W from L2)"}
-            del y2
+            del y2, y3
         except Exception as e:   # never let the side measurement take the metric down
             layer = {"error": repr(e)[:200]}
 
     if rank == 0:
-        balg = algorithmic_bytes(n, g.nnz, d, g.val is not None)
         achieved = balg / (launch_ms * 1e-3) / 1e9
         gname = "BA" if args.graph == "ba" else "HK0.3"
         workload = f"gcn_norm_sum_d{d}_{gname}_n{n}_m{args.m}" + ("_perm" if args.permute else "")
+        traffic, traffic_source = pmc_traffic(workload)
         res = {
-            "metric": "aggregated edges/sec + achieved HBM GB/s, GCN d=256 on 100M-edge scale-free",
+            "metric": METRIC,
             "value": total_nnz * args.steps / dt,
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -230,25 +264,60 @@ def main():
                                 " seed 12345+rank, symmetrised, deduplicated, self loops added" +
                                 (", nodes randomly relabelled" if args.permute else ""),
                        "index_dtype": "int32",
-                       "output_placement": {"candidate_buffers_ms": cand_ms,
-                                            "note": "fastest of 3 candidate Y buffers chosen in untimed set-up; "
-                                                    "X/Y sharing a physical HBM region costs ~12 % (DESIGN.md §5)"},
+                       "output_placement": dict(place, note="X and Y allocated once through graphgym_amd.placement "
+                                                "(the allocation ops.spmm makes for its output); no candidate loop"),
                        "parallelism": f"{world} independent graph(s), one per GPU, no data-path collective"},
             "hbm_gbps_algorithmic": achieved,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(workload),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "stream_read_gbps_measured": read_gbps, "stream_copy_gbps_measured": copy_gbps,
                          "frac_of_measured_read_stream": achieved / read_gbps,
                          "algorithmic_bytes_per_launch": balg, "launch_ms": launch_ms,
                          "launch_ms_min_median_max": [per_step[0], per_step[len(per_step) // 2], per_step[-1]],
+                         "launch_ms_p10_p90": [pct(0.1), pct(0.9)],
+                         "launch_ms_cold_median": cold[len(cold) // 2] if cold else None,
+                         "cold_note": "512 MB memset between launches (L2 / Infinity Cache flushed)",
                          "kernel": "mp::agg_rows_kernel<4,SUM,weighted> (+ hub pieces/finalize, same launch group)"},
         }
+        if backward is not None:
+            res["backward"] = backward
         if layer is not None:
             res["layer"] = layer
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(g, x)
         print(json.dumps(res), flush=True)
     D.barrier()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", choices=["aggregate", "step"], default="aggregate")
+    ap.add_argument("--nodes", type=int, default=10_000_000)
+    ap.add_argument("--m", type=int, default=5)
+    ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--graph", choices=["ba", "powerlaw_cluster"], default="ba",
+                    help="ba = Barabasi-Albert (default); powerlaw_cluster = Holme-Kim with triangle probability 0.3")
+    ap.add_argument("--permute", action="store_true", help="relabel nodes by a random permutation (seed 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--centres", type=int, default=4096, help="--mode step: ego-net centres in the global batch")
+    args = ap.parse_args()
+
+    from graphgym_amd import dist as D
+
+    rank, local, world = D.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if args.mode == "step":
+        from graphgym_amd import bench_step
+        bench_step.run(args, rank, world, dev)
+    else:
+        run_aggregate(args, rank, world, dev)
 
 
 if __name__ == "__main__":

@@ -32,6 +32,13 @@ PROTOTYPES = {
     "mp_read_probe_f32": (C.c_int, [_p, _i64, _p, _p]),
     "mp_status_str": (C.c_char_p, [C.c_int]),
     "mp_last_hip_error": (C.c_char_p, []),
+    "mp_arena_create": (C.c_int, [_sz]),
+    "mp_arena_destroy": (C.c_int, []),
+    "mp_arena_info": (C.c_int, [C.POINTER(C.c_void_p), _psz, _psz, _psz]),
+    "mp_arena_alloc_placed": (C.c_int, [_sz, _p, _i32, _sz, C.POINTER(C.c_void_p)]),
+    "mp_arena_release": (C.c_int, [_p]),
+    "mp_arena_dlpack": (C.c_int, [_p, _i32, _p, _i32, _i32, C.POINTER(C.c_void_p)]),
+    "mp_probe_copy_ms": (C.c_int, [_p, _p, _sz, _i32, C.POINTER(C.c_float), _p]),
     "mp_csr_from_coo_ws_bytes": (C.c_int, [_i64, _i64, _psz]),
     "mp_csr_from_coo": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _f32, _p, _p, _p, _p, _p, _sz, _p]),
     "mp_check_edge_index": (C.c_int, [_p, _p, _i64, _i64, _p, _p]),
@@ -44,11 +51,8 @@ PROTOTYPES = {
     "mp_stream_destroy": (C.c_int, [_p]),
     "mp_csr_scale_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "mp_mark_id_sources": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _p, _p]),
-    "mp_spmm_plan_config": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "mp_spmm_kernel_config": (C.c_int, [C.c_int, C.c_int]),
-    "mp_spmm_debug_xregions": (C.c_int, [C.c_int, _i64]),
-    "mp_spmm_plan_bytes": (C.c_int, [_i64, _i64, _psz]),
-    "mp_spmm_plan_build": (C.c_int, [_p, _i64, _i64, _p, _sz, _pi32, _p]),
+    "mp_spmm_plan_bytes": (C.c_int, [_i64, _i64, _pi32, _psz]),
+    "mp_spmm_plan_build": (C.c_int, [_p, _i64, _i64, _pi32, _p, _sz, _pi32, _p]),
     "mp_spmm_ws_bytes": (C.c_int, [_pi32, _i32, C.c_int, C.c_int, _psz]),
     "mp_spmm_csr_f32": (C.c_int, [_p, _p, _p, _i64, _p, _pi32, _p, _i64, _p, _i64, _i32, C.c_int,
                                   _p, _i64, _f32, _p, C.c_int, _p, _p, _sz, _p]),
@@ -61,10 +65,9 @@ PROTOTYPES = {
     "mp_bn_train_fwd_f32": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _f32, C.c_int, _p, _i64, _p, _p, _p, _p, _sz, _p]),
     "mp_bn_train_bwd_f32": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _p, _i64, _p, _p, _p,
                                       _sz, _p]),
-    "mp_fused_config": (C.c_int, [C.c_int, C.c_int]),
     "mp_agg_dense_f32": (C.c_int, [_p, _p, _p, _i64, C.c_int, _p, _i64, _i32, _p, _i64, C.c_float, _p, _i64, _i32, _p, C.c_int,
-                                   _p, _i64, _p, _i64, _p]),
-    "mp_dense_config": (C.c_int, [C.c_int]),
+                                   _p, _p, _i64, _p, _i64, _p]),
+    "mp_id_fixup_f32": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i32, C.c_int, _p]),
     "mp_dense_fused_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _p, _p, C.c_int, _p, _i64, _i64, _i32, _i32, _p]),
     "mp_dense_wgrad_ws_bytes": (C.c_int, [_i64, _i32, _i32, _psz]),
     "mp_dense_wgrad_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),

@@ -59,7 +59,6 @@ struct PlanCfg {
   int hub_deg;      // rows longer than this are split into pieces
   int piece_edges;  // entries per hub piece
 };
-PlanCfg plan_cfg();
 
 struct PlanView {   // host-side view of the device blob
   int32_t n_seg, cap_hub, cap_piece;
@@ -71,7 +70,5 @@ struct PlanView {   // host-side view of the device blob
   const int32_t* piece_k;    // [cap_piece]
   const int32_t* header;
 };
-PlanView plan_view(const int32_t* plan, int64_t N, int64_t nnz);
-size_t plan_words(int64_t N, int64_t nnz);
 
 }  // namespace mp

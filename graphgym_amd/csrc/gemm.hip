@@ -23,7 +23,7 @@ constexpr int BM = 128, BK = 16, APAD = 17;
 
 // TN = 32-column MFMA tiles per wave along N: block tile 128 x (64 * TN).  TN = 2 (128 columns, 3 waves per
 // SIMD) is the default; TN = 4 (256 columns: every A row read once at d <= 256) needs 297 registers, runs
-// one wave per SIMD and measured 25 % slower — kept behind mp_dense_config(4) for the record.
+// one wave per SIMD and measured 25 % slower — not built (profiles/r01_dense.log has the measurement).
 // VEC = operands allow 16-byte loads (F % 8 == 0, d % 4 == 0, aligned rows); otherwise the loaders fall back to
 // guarded scalar loads (any F, d, leading dimension: e.g. Cora's F = 1433) and everything else is unchanged.
 template <bool DUAL, int TN, bool VEC>
@@ -299,19 +299,12 @@ static int64_t wgrad_chunk(int64_t M) {
 }
 
 static bool al16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
-static int g_dense_tn = 0;   // 0 / 2 = 128-column tile (default); 4 = 256-column tile when d > 128 (tuning knob)
 
 }  // namespace mp
 
 using namespace mp;
 
 extern "C" {
-
-int mp_dense_config(int force_tn) {
-  if (force_tn != 0 && force_tn != 2 && force_tn != 4) return MP_ERR_INVALID_ARG;
-  g_dense_tn = force_tn;
-  return MP_OK;
-}
 
 int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W, const float* Q, int64_t ldq,
                        const float* Wid, const float* bias, int act, float* out, int64_t ldo, int64_t M,
@@ -322,7 +315,7 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W, const float*
   if (M == 0) return MP_OK;
   // 16-byte vector loads need operand widths in multiples of 8 (F) / 4 (d) and aligned rows; else scalar loaders
   const bool vec = !(F % 8 || d % 4 || ldp % 4 || (Q && ldq % 4)) && al16(P) && al16(W) && al16(Q) && al16(Wid);
-  const int tn = (vec && d > 128 && g_dense_tn == 4) ? 4 : 2;   // the 256-column tile fits one wave per SIMD only: slower
+  const int tn = 2;   // 128-column block tile (a 256-column tile needs 297 registers, one wave per SIMD: 25 % slower, not built)
   const int bn = 64 * tn;
   const int64_t nblocks = ceil_div(d, bn) * ceil_div(M, BM);
   if (nblocks >= INT32_MAX) return MP_ERR_UNSUPPORTED;
@@ -332,8 +325,8 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W, const float*
   hipLaunchKernelGGL((dense_fused_kernel<DUALV, TNV, VECV>), grid, dim3(kBlock), 0, st, P, ldp, W, Q, ldq, Wid, \
                      bias, act, out, ldo, M, F, d)
   if (!vec) { if (Q) MP_DENSE(true, 2, false); else MP_DENSE(false, 2, false); }
-  else if (Q) { if (tn == 4) MP_DENSE(true, 4, true); else MP_DENSE(true, 2, true); }
-  else { if (tn == 4) MP_DENSE(false, 4, true); else MP_DENSE(false, 2, true); }
+  else if (Q) MP_DENSE(true, 2, true);
+  else MP_DENSE(false, 2, true);
 #undef MP_DENSE
   MP_LAUNCH_CHECK();
   return MP_OK;

@@ -31,7 +31,6 @@ struct AggArgs {
   int32_t n_seg;
   int32_t hub_deg;
   const float* X; int64_t ldx;
-  int32_t xk; int64_t xstride;   // experiment: rows of X striped over xk memory regions (0/1 = plain row-major)
   float* Y; int64_t ldy;
   float* Q; int64_t ldq;
   const float* S; int64_t lds; float self_scale;
@@ -147,17 +146,11 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int row, int deg,
   acc.reset();
 }
 
-// Main kernel: one wave per segment of whole rows.
-// VAR bits (tuning experiments, mp_spmm_kernel_config): 1 = non-temporal stores of Y (the default, +1.3 %),
-// 2 = non-temporal loads of the index / value streams, 4 = prefetch the next 64 indices
-template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2, int U, int VAR = 1>
+// Main kernel: one wave per segment of whole rows.  Kept from the round-1 variant study: U = 8 rows
+// in flight, non-temporal stores of Y (-1.2 %); non-temporal index loads, index prefetch and an LDS-staged index
+// tile measured within 0.3 % and are not built.
+template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2, int U>
 __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
-  constexpr bool NT_ST = VAR & 1;
-  constexpr bool NT_IDX = VAR & 2;
-  constexpr bool PREF = VAR & 4;
-  constexpr bool LDS_TILE = VAR & 8;   // the index / value tile staged through LDS instead of v_readlane
-  __shared__ int lds_col[LDS_TILE ? kWavesPerBlock * kWave : 1];
-  __shared__ float lds_val[LDS_TILE ? kWavesPerBlock * kWave : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int seg = blockIdx.x * kWavesPerBlock + wave;
@@ -200,70 +193,37 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
     rend = (r < r1) ? bcast_i(rendv, r - rbase) : INT_MAX;
   };
 
-  auto load_idx = [&](int ec, int& cv, float& wv) {
-    const int me = min(ec + lane, e1 - 1);
-    if constexpr (NT_IDX) {
-      cv = __builtin_nontemporal_load(a.col + me);
-      if (WEIGHTED) wv = __builtin_nontemporal_load(a.val + me);
-    } else {
-      cv = a.col[me];
-      if (WEIGHTED) wv = a.val[me];
-    }
-  };
-  int cv = 0, cvn = 0;
-  float wv = 1.f, wvn = 1.f;
-  if constexpr (PREF) load_idx(e0, cvn, wvn);
   for (int ec = e0; ec < e1; ec += kWave) {
-    if constexpr (PREF) {
-      cv = cvn; wv = wvn;
-      if (ec + kWave < e1) load_idx(ec + kWave, cvn, wvn);
-    } else {
-      load_idx(ec, cv, wv);
-    }
+    const int me = min(ec + lane, e1 - 1);
+    const int cv = a.col[me];
+    float wv = 1.f;
+    if (WEIGHTED) wv = a.val[me];
     const int n = min(kWave, e1 - ec);
-    if constexpr (LDS_TILE) {
-      lds_col[wave * kWave + lane] = cv;
-      if (WEIGHTED) lds_val[wave * kWave + lane] = wv;
-      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is wave-private, no barrier needed
-    }
     for (int jb = 0; jb < n; jb += U) {
       float v[U][W];
       int cj[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        if constexpr (LDS_TILE) cj[j] = __builtin_amdgcn_readfirstlane(lds_col[wave * kWave + jb + j]);
-        else cj[j] = bcast_i(cv, jb + j);
+        cj[j] = bcast_i(cv, jb + j);
         const int c = BRANCH2 ? (cj[j] & 0x7fffffff) : cj[j];
-        if (a.xk > 1) {   // row c lives in region c % xk at slot c / xk (scalar arithmetic)
-          const int q = c / a.xk;
-          load_vec<W>(xlane + (int64_t)(c - q * a.xk) * a.xstride + (int64_t)q * a.ldx, v[j]);
-        } else {
-          load_vec<W>(xlane + (int64_t)c * a.ldx, v[j]);
-        }
+        load_vec<W>(xlane + (int64_t)c * a.ldx, v[j]);
       }
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         const int e = ec + jb + j;
         if (e < e1) {
           while (e >= rend) {
-            finish_row<W, REDUCE, BRANCH2, NT_ST>(a, r, rend - rstart, acc, c0, c0ld, lane_on);
+            finish_row<W, REDUCE, BRANCH2, true>(a, r, rend - rstart, acc, c0, c0ld, lane_on);
             advance();
           }
-          float w = 1.f;
-          if (WEIGHTED) {
-            if constexpr (LDS_TILE)
-              w = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
-                      __builtin_bit_cast(int, lds_val[wave * kWave + jb + j])));
-            else
-              w = bcast_f(wv, jb + j);
-          }
+          const float w = WEIGHTED ? bcast_f(wv, jb + j) : 1.f;
           acc.add(v[j], w, BRANCH2 && cj[j] < 0, e);
         }
       }
     }
   }
   while (r < r1) {
-    finish_row<W, REDUCE, BRANCH2, NT_ST>(a, r, rend - rstart, acc, c0, c0ld, lane_on);
+    finish_row<W, REDUCE, BRANCH2, true>(a, r, rend - rstart, acc, c0, c0ld, lane_on);
     advance();
   }
 }
@@ -366,8 +326,18 @@ __global__ __launch_bounds__(kBlock) void agg_hub_finalize_kernel(AggArgs a) {
 
 // ---- plan ---------------------------------------------------------------
 
-static PlanCfg g_cfg = {320, 4, 1024, 256};
-PlanCfg plan_cfg() { return g_cfg; }
+// The segmentation's tunables travel with the plan (its header words and counts_host carry them): a segment is a
+// run of whole rows of cost ~seg_cost (1 per stored entry + row_cost per row); rows with more than hub_deg entries
+// are split into pieces of piece_edges.
+static const PlanCfg kDefaultCfg = {320, 4, 1024, 256};
+
+static int cfg_from(const int32_t* cfg_host, PlanCfg* c) {
+  if (!cfg_host) { *c = kDefaultCfg; return MP_OK; }
+  PlanCfg v = {cfg_host[0], cfg_host[1], cfg_host[2], cfg_host[3]};
+  if (v.seg_cost < 64 || v.row_cost < 0 || v.hub_deg < v.seg_cost || v.piece_edges < 64) return MP_ERR_INVALID_ARG;
+  *c = v;
+  return MP_OK;
+}
 
 static int32_t n_seg_of(int64_t N, int64_t nnz, const PlanCfg& c) {
   int64_t total = nnz + (int64_t)c.row_cost * N;
@@ -375,19 +345,14 @@ static int32_t n_seg_of(int64_t N, int64_t nnz, const PlanCfg& c) {
   return (int32_t)(s < 1 ? 1 : s);
 }
 
-size_t plan_words(int64_t N, int64_t nnz) {
-  PlanCfg c = plan_cfg();
+static size_t plan_words(int64_t N, int64_t nnz, const PlanCfg& c) {
   int64_t n_seg = n_seg_of(N, nnz, c);
   int64_t cap_hub = nnz / c.hub_deg + 1;
   int64_t cap_piece = nnz / c.piece_edges + cap_hub + 1;
   return (size_t)(PW_HEADER_WORDS + (n_seg + 1) + 3 * cap_hub + 2 * cap_piece);
 }
 
-// The caps are recomputed from (N, nnz) and the *current* config, so a plan must be
-// used with the config it was built under (the header words are checked on the host
-// side through counts_host: n_seg).
-PlanView plan_view(const int32_t* plan, int64_t N, int64_t nnz) {
-  PlanCfg c = plan_cfg();
+static PlanView plan_view(const int32_t* plan, int64_t N, int64_t nnz, const PlanCfg& c) {
   PlanView v;
   v.n_seg = n_seg_of(N, nnz, c);
   v.cap_hub = (int32_t)(nnz / c.hub_deg + 1);
@@ -462,32 +427,12 @@ __global__ __launch_bounds__(kBlock) void plan_hub_kernel(const int32_t* __restr
 
 // ---- dispatch -------------------------------------------------------------
 
-static int g_xk = 0;                 // experiment knob (mp_spmm_debug_xregions)
-static int64_t g_xstride = 0;
-static int g_unroll = 8;   // rows in flight per wave (4, 8, 16)
-static int g_var = 1;      // VAR bits of agg_rows_kernel
-
 template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2>
 static int launch_agg(const AggArgs& a, int64_t N, const int32_t* counts, hipStream_t st) {
   constexpr int U = 8;
   const int tiles = (int)ceil_div(a.d, kWave * W);
   dim3 grid((unsigned)ceil_div(a.n_seg, kWavesPerBlock), (unsigned)tiles);
-  bool launched = false;
-  if constexpr (W == 4 && REDUCE == MP_SUM && WEIGHTED && !BRANCH2) {
-    // tuning variants exist for the headline instantiation only (mp_spmm_kernel_config)
-#define MP_VARIANT(UU, VV)                                                                          \
-    if (!launched && g_unroll == UU && g_var == VV) {                                               \
-      hipLaunchKernelGGL((agg_rows_kernel<W, REDUCE, WEIGHTED, BRANCH2, UU, VV>), grid, dim3(kBlock), \
-                         0, st, a);                                                                 \
-      launched = true;                                                                              \
-    }
-    MP_VARIANT(4, 0) MP_VARIANT(16, 0) MP_VARIANT(8, 0) MP_VARIANT(8, 2) MP_VARIANT(8, 3)
-    MP_VARIANT(8, 4) MP_VARIANT(8, 5) MP_VARIANT(8, 7) MP_VARIANT(16, 7) MP_VARIANT(16, 1) MP_VARIANT(4, 7)
-    MP_VARIANT(8, 9)
-#undef MP_VARIANT
-  }
-  if (!launched)
-    hipLaunchKernelGGL((agg_rows_kernel<W, REDUCE, WEIGHTED, BRANCH2, U>), grid, dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((agg_rows_kernel<W, REDUCE, WEIGHTED, BRANCH2, U>), grid, dim3(kBlock), 0, st, a);
   MP_LAUNCH_CHECK();
   const int n_hub = counts[1], n_piece = counts[2];
   if (n_hub > 0) {
@@ -579,7 +524,6 @@ static int agg_common(const int32_t* rowptr, const int32_t* col, const float* va
   a.hub_deg = counts[6];       // the config the plan was built under
   a.piece_edges = counts[7];
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.Q = Q; a.ldq = ldq;
-  a.xk = g_xk; a.xstride = g_xstride;
   a.S = S; a.lds = lds; a.self_scale = self_scale; a.bias = bias; a.act = act;
   a.col_scale = col_scale; a.l2norm = l2norm; a.l2_eps = l2_eps;
   a.argmax = argmax; a.d = d;
@@ -634,46 +578,25 @@ using namespace mp;
 
 extern "C" {
 
-int mp_spmm_plan_config(int seg_cost, int row_cost, int hub_deg, int piece_edges) {
-  if (seg_cost < 64 || row_cost < 0 || hub_deg < seg_cost || piece_edges < 64) return MP_ERR_INVALID_ARG;
-  g_cfg = {seg_cost, row_cost, hub_deg, piece_edges};
-  return MP_OK;
-}
-
-// EXPERIMENT (layout study): the main aggregation kernel reads row c of X at
-// X + (c % k) * stride_floats + (c / k) * ldx, i.e. rows striped over k memory regions.  k <= 1 restores
-// the plain row-major addressing.  Hub rows keep plain addressing, so only use it for timing studies.
-int mp_spmm_debug_xregions(int k, int64_t stride_floats) {
-  if (k < 0 || k > 64 || stride_floats < 0) return MP_ERR_INVALID_ARG;
-  g_xk = k;
-  g_xstride = stride_floats;
-  return MP_OK;
-}
-
-int mp_spmm_kernel_config(int rows_in_flight, int variant_bits) {
-  if (rows_in_flight != 4 && rows_in_flight != 8 && rows_in_flight != 16) return MP_ERR_INVALID_ARG;
-  if (variant_bits < 0 || variant_bits > 15) return MP_ERR_INVALID_ARG;
-  g_unroll = rows_in_flight;
-  g_var = variant_bits;
-  return MP_OK;
-}
-
-int mp_spmm_plan_bytes(int64_t N, int64_t nnz, size_t* bytes_host) {
+int mp_spmm_plan_bytes(int64_t N, int64_t nnz, const int32_t* cfg_host, size_t* bytes_host) {
   if (!bytes_host || N < 0 || nnz < 0) return MP_ERR_INVALID_ARG;
   if (nnz >= INT32_MAX || N >= INT32_MAX) return MP_ERR_UNSUPPORTED;
-  *bytes_host = plan_words(N, nnz) * sizeof(int32_t);
+  PlanCfg c;
+  if (int st = cfg_from(cfg_host, &c)) return st;
+  *bytes_host = plan_words(N, nnz, c) * sizeof(int32_t);
   return MP_OK;
 }
 
 // counts_host: {n_seg, n_hub, n_piece, cap_hub, cap_piece, seg_cost, hub_deg, piece_edges}
-int mp_spmm_plan_build(const int32_t* rowptr, int64_t N, int64_t nnz, int32_t* plan,
+int mp_spmm_plan_build(const int32_t* rowptr, int64_t N, int64_t nnz, const int32_t* cfg_host, int32_t* plan,
                        size_t plan_bytes, int32_t* counts_host, mp_stream_t stream) {
   if (!rowptr || !plan || !counts_host || N < 0 || nnz < 0) return MP_ERR_INVALID_ARG;
   if (nnz >= INT32_MAX || N >= INT32_MAX) return MP_ERR_UNSUPPORTED;
-  if (plan_bytes < plan_words(N, nnz) * sizeof(int32_t)) return MP_ERR_WORKSPACE;
+  PlanCfg c;
+  if (int cst = cfg_from(cfg_host, &c)) return cst;
+  if (plan_bytes < plan_words(N, nnz, c) * sizeof(int32_t)) return MP_ERR_WORKSPACE;
   hipStream_t st = as_stream(stream);
-  const PlanCfg c = plan_cfg();
-  PlanView v = plan_view(plan, N, nnz);
+  PlanView v = plan_view(plan, N, nnz, c);
   hipLaunchKernelGGL(plan_header_kernel, dim3(1), dim3(64), 0, st, plan, v.n_seg, c, v.cap_hub,
                      v.cap_piece);
   MP_LAUNCH_CHECK();

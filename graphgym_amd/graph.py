@@ -47,10 +47,12 @@ class CSRGraph:
     @classmethod
     def from_edge_index(cls, edge_index, num_nodes, edge_weight=None, *, dst_row=1,
                         remove_self_loops=False, add_self_loops=False, keep_loop_weight=False,
-                        fill=1.0, validate=False):
+                        fill=1.0, validate=True):
         """edge_index: LongTensor [2, E] on the GPU.  dst_row=1 is PyG's
         source_to_target flow (edge_index[1] = destination i); dst_row=0 is the
-        TF path's SparseAdj convention (edge_index[0] = row = destination)."""
+        TF path's SparseAdj convention (edge_index[0] = row = destination).
+        validate (default): node ids outside [0, num_nodes) raise ValueError, as indexing does in the reference,
+        instead of becoming out-of-range column indices for the kernels (one E-sized pass; the CSR is cached per batch)."""
         _require_hip(edge_index, "edge_index")
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError("edge_index must be [2, E]")
@@ -112,8 +114,8 @@ class CSRGraph:
         if stamp not in cache:
             if len(cache) > 8:
                 cache.clear()
-            cache[stamp] = self._select_rows(rows)
-        return cache[stamp]
+            cache[stamp] = (self._select_rows(rows), rows)    # holding `rows` keeps its address from being reused
+        return cache[stamp][0]
 
     def _select_rows(self, rows):
         rows = rows.to(torch.int64)
@@ -141,6 +143,10 @@ class CSRGraph:
         return self.rowptr.device
 
     # ---- plan --------------------------------------------------------------
+    # segmentation tunables {seg_cost, row_cost, hub_deg, piece_edges} handed to mp_spmm_plan_build per call
+    # (None = the library's defaults); tests shrink them to push small graphs through the hub path
+    PLAN_CONFIG = None
+
     def plan(self):
         if self._plan is None:
             src = getattr(self, "_pattern_of", None)
@@ -150,10 +156,11 @@ class CSRGraph:
             L = lib()
             with torch.cuda.device(self.device):
                 nb = C.c_size_t(0)
-                check(L.mp_spmm_plan_bytes(self.num_nodes, self.nnz, C.byref(nb)))
+                cfg = None if CSRGraph.PLAN_CONFIG is None else (C.c_int32 * 4)(*CSRGraph.PLAN_CONFIG)
+                check(L.mp_spmm_plan_bytes(self.num_nodes, self.nnz, cfg, C.byref(nb)))
                 blob = torch.empty(nb.value // 4, dtype=torch.int32, device=self.device)
                 counts = (C.c_int32 * 8)()
-                check(L.mp_spmm_plan_build(ptr(self.rowptr), self.num_nodes, self.nnz, ptr(blob),
+                check(L.mp_spmm_plan_build(ptr(self.rowptr), self.num_nodes, self.nnz, cfg, ptr(blob),
                                            nb.value, counts, _stream()), "mp_spmm_plan_build")
             self._plan = (blob, counts)
         return self._plan
@@ -237,6 +244,8 @@ class CSRGraph:
 
     def degree(self, axis="row"):
         L = lib()
+        if axis != "row" and self.num_cols != self.num_nodes:
+            raise ValueError("degree('col') needs a square operator")
         deg = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             check(L.mp_csr_degree(ptr(self.rowptr), ptr(self.col), ptr(self.val), self.num_nodes, self.nnz,
@@ -279,15 +288,69 @@ class CSRGraph:
         if stamp not in cache:
             if len(cache) > 8:
                 cache.clear()
-            cache[stamp] = self._mark_ids(id_index)
-        return cache[stamp]
+            cache[stamp] = (self._mark_ids(id_index), id_index)   # holding the tensor keeps its address unique
+        return cache[stamp][0]
+
+    def id_branch(self, id_index):
+        """The stored entries whose SOURCE is an identity node, as two compact operators (cached per index tensor):
+        A_id = this operator restricted to the identity columns.  A S X W_id of gcn_id (TfgIDLayer.py:510-517) equals
+        A_id Z with Z = X[id] W_id, so the identity branch is a small product plus these few entries.
+
+        Returns an object with: rows [n_m] int32 (ascending rows that own such an entry), crp [n_m + 1] int32,
+        slot [n_e] int32 (position of the entry's source in id_index), val [n_e] fp32 or None, defer [N] uint8
+        (1 on `rows`), and t: A_id^T as a CSRGraph [n_id x N] (for the backward pass)."""
+        _require_hip(id_index, "id_index")
+        stamp = (id_index.data_ptr(), id_index.numel(), id_index._version)
+        cache = self.__dict__.setdefault("_id_branch", {})
+        if stamp not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[stamp] = (self._id_branch_build(id_index), id_index)
+        return cache[stamp][0]
+
+    def _id_branch_build(self, id_index):
+        import types
+        dev = self.device
+        ids = id_index.to(torch.int64)
+        n_id, N = ids.numel(), self.num_nodes
+        if n_id and (int(ids.min()) < 0 or int(ids.max()) >= self.num_cols):
+            raise ValueError(f"id_index has entries outside [0, {self.num_cols})")
+        if torch.unique(ids).numel() != n_id:
+            raise ValueError("id_index has duplicate entries; the fused identity branch needs unique identity nodes "
+                             "(use order='transform_first')")
+        slot_of = torch.full((max(self.num_cols, 1),), -1, dtype=torch.int32, device=dev)
+        slot_of[ids] = torch.arange(n_id, dtype=torch.int32, device=dev)
+        s = slot_of[self.col.long()] if self.nnz else slot_of[:0]
+        e_idx = torch.nonzero(s >= 0).view(-1)                      # ascending = CSR order
+        rows_e = self.row_ids()[e_idx]
+        rows_m, counts = torch.unique_consecutive(rows_e, return_counts=True)
+        crp = torch.zeros(rows_m.numel() + 1, dtype=torch.int32, device=dev)
+        crp[1:] = torch.cumsum(counts, 0)
+        slot = s[e_idx].contiguous()
+        val = None if self.val is None else self.val[e_idx].contiguous()
+        defer = torch.zeros(max(N, 1), dtype=torch.uint8, device=dev)
+        defer[rows_m.long()] = 1
+        order = torch.sort(slot.long(), stable=True).indices
+        t_rowptr = torch.zeros(n_id + 1, dtype=torch.int32, device=dev)
+        t_rowptr[1:] = torch.cumsum(torch.bincount(slot.long(), minlength=n_id), 0)
+        t = CSRGraph(t_rowptr, rows_e[order].contiguous().to(torch.int32),
+                     None if val is None else val[order].contiguous(), None, n_id, int(e_idx.numel()), N)
+        return types.SimpleNamespace(rows=rows_m.to(torch.int32).contiguous(), crp=crp, slot=slot, val=val,
+                                     defer=defer, t=t, n_rows=int(rows_m.numel()))
 
     def _mark_ids(self, id_index):
         L = lib()
         ids = id_index.to(torch.int64).contiguous()
-        flag = torch.empty(max(self.num_nodes, 1), dtype=torch.uint8, device=self.device)
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.num_cols):
+            raise ValueError(f"id_index has entries outside [0, {self.num_cols})")
+        if torch.unique(ids).numel() != ids.numel():
+            # the mark is a set: a node listed k times would count once here but k times in the reference's
+            # tensor_scatter_nd_add / index_add_ (TfgIDLayer.py:515, idconv.py:155)
+            raise ValueError("id_index has duplicate entries; the two-branch aggregation needs unique identity nodes "
+                             "(use order='transform_first')")
+        flag = torch.empty(max(self.num_cols, 1), dtype=torch.uint8, device=self.device)
         out = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            check(L.mp_mark_id_sources(ptr(self.col), self.nnz, ptr(ids), ids.numel(), self.num_nodes,
+            check(L.mp_mark_id_sources(ptr(self.col), self.nnz, ptr(ids), ids.numel(), self.num_cols,
                                        ptr(flag), ptr(out), _stream()), "mp_mark_id_sources")
         return out[:self.nnz]

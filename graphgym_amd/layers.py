@@ -61,7 +61,7 @@ def get_graph(holder, edge_index, num_nodes, *, dst_row=1, loops="none", norm=No
         stamp = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes))
         cache = getattr(holder, "_mp_graph_cache", None)
         if cache is None or cache.get("stamp") != stamp:
-            cache = {"stamp": stamp}
+            cache = {"stamp": stamp, "edge_index": edge_index}     # holding the tensor keeps its address unique
             try:
                 setattr(holder, "_mp_graph_cache", cache)
             except Exception:
@@ -120,6 +120,15 @@ def _fused_mlp_head(mlp, g, x, self_scale):
     for m in list(mlp)[2 if next_relu else 1:]:
         h = m(h)
     return h
+
+
+def _id_mlp_rows(out, g, x, id_index, mlp_id, self_scale):
+    """out[id] += MLP_id(h[id]) (TfgIDLayer.py:160-165, idconv.py:373-375) when h = (1 + eps) x + sum_j x_j was never
+    materialised (the one-kernel head): the identity nodes' rows of h are re-aggregated over their own in-edges only
+    (an [n_id, N] operator)"""
+    sub = g.select_rows(id_index)
+    h_id = ops.spmm(sub, x, "sum") + self_scale * ops.gather_rows(x, id_index)
+    return ops.index_add_rows(out, id_index, mlp_id(h_id))
 
 
 # =========================================================================================
@@ -183,6 +192,9 @@ class GCNIDConvLayer(nn.Module, _CachedEdgesMixin):
             g = self._graph(holder, edge_index, x.size(0), edge_weight, loops="none")
         order = _pick_order(self.order, self.in_channels, self.out_channels)
         if order == "aggregate_first" and self._agg in ("add", "sum"):
+            out = ops.agg_dense_id(g, x, self.weight, self.weight_id, id, self.bias)   # one launch + the identity fix-up
+            if out is not None:
+                return out
             P, Q = ops.idgnn_aggregate(g, id, x)
             return ops.dense_fused(P, self.weight, Q, self.weight_id, self.bias)   # P W + Q W_id + b, one kernel
         h = _id_branch(ops.dense_fused(x, self.weight), x, id, self.weight_id)
@@ -360,19 +372,23 @@ class GINIDConvLayer(nn.Module):
 
     _loops = "remove"
 
+    def _eps_value(self):
+        # the registered buffer (a loaded state_dict may carry another eps than the constructor's)
+        return float(self.eps)
+
     def _combine(self, g, x):
         # (1 + eps) * x + sum_j x_j ; with a constant eps the self term rides in the aggregation's epilogue
         if self.train_eps:
             return (1 + self.eps) * x + ops.spmm(g, x, "sum")
-        return ops.spmm(g, x, "sum", self_scale=1.0 + float(self.initial_eps))
+        return ops.spmm(g, x, "sum", self_scale=1.0 + self._eps_value())
 
     def forward(self, x, edge_index, id, holder=None):
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         g = get_graph(holder, edge_index, x.size(0), loops=self._loops)
-        if id is None and not self.train_eps:
-            out = _fused_mlp_head(self.nn, g, x, 1.0 + float(self.initial_eps))
+        if not self.train_eps:
+            out = _fused_mlp_head(self.nn, g, x, 1.0 + self._eps_value())
             if out is not None:
-                return out
+                return out if id is None else _id_mlp_rows(out, g, x, id, self.nn_id, 1.0 + self._eps_value())
         h = self._combine(g, x)
         out = self.nn(h)
         if id is not None:
@@ -646,8 +662,10 @@ class IDGCN(_KerasLike):
         order = _pick_order(self.order, self.in_features, self.units)
         if order == "aggregate_first":
             if id_index is not None:
-                P, Q = ops.idgnn_aggregate(g, id_index, x)
-                h = ops.dense_fused(P, self.kernel, Q, self.kernel_id, self.bias, relu=relu)
+                h = ops.agg_dense_id(g, x, self.kernel, self.kernel_id, id_index, self.bias, relu=relu)
+                if h is None:
+                    P, Q = ops.idgnn_aggregate(g, id_index, x)
+                    h = ops.dense_fused(P, self.kernel, Q, self.kernel_id, self.bias, relu=relu)
             else:
                 h = ops.agg_dense(g, x, self.kernel, bias=self.bias, relu=relu)
             return h if relu else _apply_act(h, self.activation)
@@ -735,10 +753,10 @@ class IDGIN(_KerasLike):
     def call(self, inputs, cache=None, training=None, mask=None, holder=None):
         x, edge_index, id_index, _ = _unpack(inputs, self.with_id)   # edge weights ignored (:150-151)
         g = get_graph(holder, edge_index, x.size(0), dst_row=0, loops="none")
-        if id_index is None and not self.train_eps:
+        if not self.train_eps:
             out = _fused_mlp_head(self.mlp_model, g, x, 1.0 + float(self.eps))
             if out is not None:
-                return out
+                return out if id_index is None else _id_mlp_rows(out, g, x, id_index, self.mlp_id, 1.0 + float(self.eps))
         if self.train_eps:
             h = x * (1.0 + self.eps) + ops.spmm(g, x, "sum")
         else:

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import placement
 from ._lib import check, lib, ptr
 from .graph import _require_hip, _stream
 
@@ -23,7 +24,7 @@ class _BatchNormAct(torch.autograd.Function):
         x = x if (x.dtype == torch.float32 and x.stride(-1) == 1) else x.float().contiguous()
         L = lib()
         N, d = x.shape
-        y = torch.empty((N, d), dtype=torch.float32, device=x.device)
+        y = placement.empty_or_torch((N, d), x.device, reads=(x,))
         mean = torch.empty(d, dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
         var_u = torch.empty_like(mean)
@@ -48,7 +49,7 @@ class _BatchNormAct(torch.autograd.Function):
         L = lib()
         N, d = x.shape
         dy = dy.contiguous()
-        dx = torch.empty((N, d), dtype=torch.float32, device=x.device)
+        dx = placement.empty_or_torch((N, d), x.device, reads=(dy, x))
         dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
         dbeta = torch.empty_like(dgamma)
         with torch.cuda.device(x.device):

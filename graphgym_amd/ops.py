@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, placement
 from ._lib import check, lib, ptr
 from .graph import CSRGraph, _require_hip, _stream
 
@@ -28,7 +28,7 @@ def _raw_spmm(g, x, reduce, S=None, self_scale=0.0, bias=None, relu=False, want_
     """one launch of mp_spmm_csr_f32; x [n_src, d] -> y [N, d] (written into `out` when given)"""
     L = lib()
     N, d = g.num_nodes, x.size(1)
-    y = out if out is not None else torch.empty((N, d), dtype=torch.float32, device=x.device)
+    y = out if out is not None else placement.empty_or_torch((N, d), x.device, reads=(x,))
     argmax = torch.empty((N, d), dtype=torch.int32, device=x.device) if want_argmax else None
     plan, counts = g.plan()
     with torch.cuda.device(x.device):
@@ -136,8 +136,8 @@ class _IdAgg(torch.autograd.Function):
         x = _f32c(x, "x")
         L = lib()
         N, d = g.num_nodes, x.size(1)
-        P = torch.empty((N, d), dtype=torch.float32, device=x.device)
-        Q = torch.empty((N, d), dtype=torch.float32, device=x.device)
+        P = placement.empty_or_torch((N, d), x.device, reads=(x,))
+        Q = placement.empty_or_torch((N, d), x.device, reads=(x,))
         plan, counts = g.plan()
         with torch.cuda.device(x.device):
             nb = C.c_size_t(0)
@@ -177,7 +177,7 @@ def _raw_dense_fused(P, W, Q, W_id, bias, relu):
     L = lib()
     M, F = P.shape
     d = W.size(1)
-    out = torch.empty((M, d), dtype=torch.float32, device=P.device)
+    out = placement.empty_or_torch((M, d), P.device, reads=(P, Q))
     Wc = W.contiguous()
     Wi = None if W_id is None else W_id.contiguous()
     b = None if bias is None else bias.contiguous()
@@ -191,7 +191,7 @@ def _raw_dense_fused(P, W, Q, W_id, bias, relu):
     return out
 
 
-FUSED_WIDTHS = (64, 128, 256)
+FUSED_WIDTHS = (64, 128, 256, 512)
 FUSED_MAX_ROW = 1 << 18      # longer rows (star-like hubs) go to the plan-based kernel, which spreads them over many waves
 
 
@@ -201,24 +201,25 @@ def agg_dense_supported(g, x, W):
     if os.environ.get("MP_FUSED", "1") == "0":
         return False
     return (x.size(1) in FUSED_WIDTHS and W.size(1) % 2 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and (x.size(1) < 512 or W.size(1) <= 512)
             and g.nnz > 0 and g.max_row_entries() <= FUSED_MAX_ROW)
 
 
 def _raw_agg_dense(g, x, W, bias=None, relu=False, S=None, self_scale=0.0, want_P=False, reduce=_lib.SUM,
-                   out=None):
+                   out=None, defer_act=None):
     """out = act((reduce_j w_ij x[j] + self_scale * S) W + bias) in one launch (into the view `out` when given);
-    returns (out, P or None) with P the aggregated rows"""
+    returns (out, P or None) with P the aggregated rows; defer_act [N] uint8: rows stored without the activation"""
     L = lib()
     N, F, d = g.num_nodes, x.size(1), W.size(1)
     Wc = W.contiguous()
     b = None if bias is None else bias.contiguous()
     if out is None:
-        out = torch.empty((N, d), dtype=torch.float32, device=x.device)
-    P = torch.empty((N, F), dtype=torch.float32, device=x.device) if want_P else None
+        out = placement.empty_or_torch((N, d), x.device, reads=(x,))
+    P = placement.empty_or_torch((N, F), x.device, reads=(x,)) if want_P else None
     with torch.cuda.device(x.device):
         check(L.mp_agg_dense_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val), N, reduce, ptr(x), x.stride(0), F,
                                  ptr(S), S.stride(0) if S is not None else 0, float(self_scale), ptr(Wc),
-                                 Wc.stride(0), d, ptr(b), _lib.ACT_RELU if relu else _lib.ACT_NONE,
+                                 Wc.stride(0), d, ptr(b), _lib.ACT_RELU if relu else _lib.ACT_NONE, ptr(defer_act),
                                  ptr(P), P.stride(0) if P is not None else 0, ptr(out), out.stride(0), _stream()),
               "mp_agg_dense_f32")
     return out, P
@@ -337,6 +338,67 @@ class _AggDense(torch.autograd.Function):
                 T, _ = _raw_spmm(gt, gm, _lib.SUM, S=S, self_scale=ctx.self_scale)
                 dx = torch.mm(T, Wt)
         return dx, dW, db, None, None, None, None
+
+
+class _AggDenseID(torch.autograd.Function):
+    """out = act(A (x W + S x W_id) + b) = act((A x) W + b + A_id Z), Z = x[id] W_id  (gcn_id, TfgIDLayer.py:510-523;
+    GCNIDConvLayer.forward, idconv.py:150-177): the one-kernel aggregate -> transform plus the identity branch as a
+    small product and a fix-up of the few rows next to an identity node (mp_id_fixup_f32).  Backward: the same
+    kernel on the transposed operator for dx, and the identity branch through A_id^T g (an [n_id, N] aggregation)."""
+    @staticmethod
+    def forward(ctx, x, W, W_id, bias, g, ids, self_scale, relu, grad_mode):
+        x = _f32c(x, "x")
+        if x.size(0) != g.num_cols or g.num_cols != g.num_nodes:
+            raise ValueError("the identity branch needs a square operator over the rows of x")
+        br = g.id_branch(ids)
+        ids = ids.to(torch.int64)
+        x_id = x.index_select(0, ids)
+        Z = torch.mm(x_id, W_id.detach())
+        need_w = ctx.needs_input_grad[1] and grad_mode
+        out, P = _raw_agg_dense(g, x, W.detach(), None if bias is None else bias.detach(), relu,
+                                S=x if self_scale != 0.0 else None, self_scale=self_scale, want_P=need_w,
+                                defer_act=br.defer)
+        with torch.cuda.device(x.device):
+            check(lib().mp_id_fixup_f32(ptr(br.rows), ptr(br.crp), ptr(br.slot), ptr(br.val), br.n_rows, ptr(Z),
+                                        Z.stride(0), ptr(out), out.stride(0), out.size(1),
+                                        _lib.ACT_RELU if relu else _lib.ACT_NONE, _stream()), "mp_id_fixup_f32")
+        ctx.g, ctx.br, ctx.self_scale, ctx.relu, ctx.has_bias = g, br, self_scale, relu, bias is not None
+        ctx.save_for_backward(P, W, W_id, x_id, ids, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        P, W, W_id, x_id, ids, out = ctx.saved_tensors
+        gm = gout.contiguous()
+        if ctx.relu:
+            gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
+        dW, db = _wgrad_and_bias(P, gm, ctx.needs_input_grad[1], ctx.has_bias)
+        # identity branch: T = A_id^T g  [n_id, d_out];  dW_id = x_id^T T ;  dx[id] += T W_id^T
+        T = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            T, _ = _raw_spmm(ctx.br.t, gm, _lib.SUM)
+        dWid = torch.mm(x_id.t(), T) if ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            gt = ctx.g.transpose()
+            Wt = W.detach().t().contiguous()
+            S = gm if ctx.self_scale != 0.0 else None
+            if agg_dense_supported(gt, gm, Wt):
+                dx, _ = _raw_agg_dense(gt, gm, Wt, None, False, S=S, self_scale=ctx.self_scale)
+            else:
+                A, _ = _raw_spmm(gt, gm, _lib.SUM, S=S, self_scale=ctx.self_scale)
+                dx = torch.mm(A, Wt)
+            dx.index_add_(0, ids, torch.mm(T, W_id.detach().t()))
+        return dx, dW, dWid, db, None, None, None, None, None
+
+
+def agg_dense_id(g, x, W, W_id, id_index, bias=None, relu=False, self_scale=0.0):
+    """act(A (x W + S x W_id) + bias) with S selecting the identity nodes' rows: one aggregate -> transform launch plus
+    the identity branch's small product and row fix-up; None when the shapes are outside the one-kernel layer (the
+    caller then runs idgnn_aggregate + dense_fused)"""
+    if not (agg_dense_supported(g, x, W) and x.dtype == torch.float32 and g.num_cols == g.num_nodes):
+        return None
+    return _AggDenseID.apply(x, W, W_id, bias, g, id_index, float(self_scale), bool(relu), torch.is_grad_enabled())
 
 
 def agg_dense(g, x, W, bias=None, relu=False, self_scale=0.0):

@@ -35,18 +35,33 @@ class SparseAdj(object):
         return self.edge_index[1]
 
     def csr(self):
-        """the engine-side graph (built once): rows = destinations, values = edge_weight"""
+        """the engine-side graph (built once): rows = destinations, values = edge_weight (detached: kernels read the
+        numbers; gradients w.r.t. edge_weight flow through the differentiable operators below)"""
         if self._csr is None:
             if self.shape[0] != self.shape[1]:
                 raise ValueError("square adjacency expected")
-            self._csr = CSRGraph.from_edge_index(self.edge_index, self.shape[0], self.edge_weight, dst_row=0)
+            self._csr = CSRGraph.from_edge_index(self.edge_index, self.shape[0], self.edge_weight, dst_row=0,
+                                                 validate=True)
         return self._csr
 
-    def _from_csr_values(self, g):
-        """COO-order weights of a graph that shares this adjacency's pattern"""
-        w = torch.empty_like(self.edge_weight)
-        w[g.eid.long()] = g.val
-        return SparseAdj(self.edge_index, w, self.shape, _csr=g)
+    def _needs_grad(self, *others):
+        return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (self.edge_weight,) + others)
+
+    def _coo_pos(self, g):
+        """position in the CSR of every COO entry (inverse of g.eid), cached on the pattern"""
+        owner = getattr(g, "_pattern_of", None) or g
+        pos = owner.__dict__.get("_coo_pos")
+        if pos is None:
+            pos = torch.empty(g.nnz, dtype=torch.int64, device=g.device)
+            pos[g.eid.long()] = torch.arange(g.nnz, device=g.device)
+            owner.__dict__["_coo_pos"] = pos
+        return pos
+
+    def _with_weights(self, g, w_csr):
+        """a SparseAdj over the same pattern whose weights are w_csr (CSR order, may carry a gradient graph)"""
+        gv = g.with_values(w_csr.detach().contiguous())
+        gv.eid = g.eid
+        return SparseAdj(self.edge_index, w_csr[self._coo_pos(g)], self.shape, _csr=gv)
 
     def add_self_loop(self, fill_weight=1.0):                      # sparse_adj.py:58-63
         n = self.shape[0]
@@ -57,15 +72,23 @@ class SparseAdj(object):
 
     def reduce_sum(self, axis=-1, keepdims=False):                 # sparse_adj.py:65-85
         if axis in (-1, 1):
-            out = self.csr().degree("row")
+            which = 0
         elif axis in (0, -2):
-            out = self.csr().degree("col")
+            which = 1
         else:
             raise Exception("Invalid axis value: {}, axis shoud be -1, -2, 0, or 1".format(axis))
+        if self._needs_grad():       # differentiable in edge_weight: unsorted_segment_sum as torch autograd sees it
+            out = torch.zeros(self.shape[which], dtype=torch.float32, device=self.edge_weight.device)
+            out = out.index_add(0, self.edge_index[which], self.edge_weight)
+        else:
+            out = self.csr().degree("row" if which == 0 else "col")
         return out.unsqueeze(axis) if keepdims else out
 
     def matmul(self, h):                                           # sparse_adj.py:91-97
-        return ops.spmm(self.csr(), h, "sum")
+        g = self.csr()
+        if self._needs_grad():       # gradient to the weights too: gat_id's softmax(scores) @ V (TfgIDLayer.py:340-355)
+            return ops.spmm_edge_values(g, self.edge_weight[g.eid.long()].view(-1, 1), h, 1)
+        return ops.spmm(g, h, "sum")
 
     def __matmul__(self, h):
         return self.matmul(h)
@@ -74,10 +97,16 @@ class SparseAdj(object):
         return (self.transpose() @ h.t().contiguous()).t()
 
     def matmul_diag(self, diagonal):                               # sparse_adj.py:110-113
-        return self._from_csr_values(self.csr().scaled(col_scale=diagonal))
+        if self._needs_grad(diagonal):
+            return SparseAdj(self.edge_index, self.edge_weight * diagonal[self.col], self.shape)
+        g = self.csr()
+        return self._with_weights(g, g.scaled(col_scale=diagonal).val)
 
     def rmatmul_diag(self, diagonal):                              # sparse_adj.py:116-119
-        return self._from_csr_values(self.csr().scaled(row_scale=diagonal))
+        if self._needs_grad(diagonal):
+            return SparseAdj(self.edge_index, diagonal[self.row] * self.edge_weight, self.shape)
+        g = self.csr()
+        return self._with_weights(g, g.scaled(row_scale=diagonal).val)
 
     def transpose(self):                                           # sparse_adj.py:124-127
         return SparseAdj(torch.stack([self.col, self.row]), self.edge_weight, self.shape)
@@ -89,8 +118,8 @@ class SparseAdj(object):
     def softmax(self, axis=-1):                                    # sparse_adj.py:136-151
         if axis in (-1, 1):
             g = self.csr()
-            p = ops.edge_softmax(g, g.val.view(-1, 1)).view(-1)
-            return self._from_csr_values(g.with_values(p))
+            w_csr = self.edge_weight[g.eid.long()] if self._needs_grad() else g.val
+            return self._with_weights(g, ops.edge_softmax(g, w_csr.view(-1, 1)).view(-1))
         if axis in (0, -2):
             return self.transpose().softmax(-1).transpose()
         raise Exception("Invalid axis value: {}, axis shoud be -1, -2, 0, or 1".format(axis))

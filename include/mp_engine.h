@@ -78,6 +78,38 @@ const char* mp_status_str(int status);
 const char* mp_last_hip_error(void);
 
 /* ------------------------------------------------------------------ *
+ * Placement-aware device arena (no counterpart in the reference: it     *
+ * never places anything; this is the path's data layout in HBM).        *
+ * On MI355X a launch that reads X and writes Y is up to ~15 % slower     *
+ * depending on which physical memory backs the two (the high address    *
+ * bits are hashed into the DRAM bank / channel selection; measured map: *
+ * profiles/r02_placement_map.log).  The engine owns one slab per        *
+ * device, measures the pairwise cost between its granules once          *
+ * (mp_probe_copy_ms, driven by graphgym_amd/placement.py) and places    *
+ * the outputs of mp_spmm_csr_f32 / mp_agg_dense_f32 / mp_idgnn_agg_f32   *
+ * where they conflict least with what the launch reads.                 *
+ * Exception to "nothing is allocated inside the library": the slab is   *
+ * one hipMalloc in mp_arena_create, released by mp_arena_destroy.       *
+ * All of these act on the calling thread's current HIP device.          *
+ * ------------------------------------------------------------------ */
+int mp_arena_create(size_t bytes);
+int mp_arena_destroy(void);      /* MP_ERR_INVALID_ARG while buffers are handed out */
+int mp_arena_info(void** base_host, size_t* bytes_host, size_t* in_use_host, size_t* largest_free_host);
+/* a free range of `bytes` (rounded up to 2 MiB) with the smallest mean penalty; penalty_host[g] prices granule g =
+ * bytes [g * granule_bytes, (g + 1) * granule_bytes) of the slab, NULL = first fit; ties go to the lowest address;
+ * MP_ERR_WORKSPACE when no free run is large enough */
+int mp_arena_alloc_placed(size_t bytes, const float* penalty_host, int32_t n_granules, size_t granule_bytes,
+                          void** ptr_host);
+int mp_arena_release(void* ptr);
+/* DLManagedTensor* (DLPack) over an arena buffer for torch.from_dlpack: contiguous, 1-4 dims, DLPack element type
+ * (code, bits) — float32 = (2, 32); its deleter calls mp_arena_release.  Consume *managed_host exactly once. */
+int mp_arena_dlpack(void* ptr, int32_t ndim, const int64_t* shape_host, int32_t type_code, int32_t type_bits,
+                    void** managed_host);
+/* timed streaming copy (16 B per lane, non-temporal stores): one untimed launch, then `reps` launches between
+ * two events; SYNCHRONISES `stream`; *ms_host = mean milliseconds per launch */
+int mp_probe_copy_ms(const void* src, void* dst, size_t bytes, int32_t reps, float* ms_host, mp_stream_t stream);
+
+/* ------------------------------------------------------------------ *
  * Graph construction: COO edge list -> destination-sorted CSR         *
  * replaces: SparseAdj.__init__/add_self_loop (sparse_adj.py:18-63),   *
  *   add_remaining_self_loops / remove_self_loops / add_self_loops     *
@@ -156,23 +188,14 @@ int mp_mark_id_sources(const int32_t* col, int64_t nnz, const int64_t* id_index,
  * Aggregation plan: nnz-balanced row segments + split of hub rows     *
  * (no counterpart in the reference; built once per graph and cached)  *
  * ------------------------------------------------------------------ */
-/* tunables of the segmentation (process-wide; a plan must be used under the config it
- * was built with — its counts carry that config): a segment is a run of whole rows of
- * cost ~seg_cost (1 per stored entry + row_cost per row); rows with more than hub_deg
- * entries are split into pieces of piece_edges.  Defaults 320 / 4 / 1024 / 256. */
-int mp_spmm_plan_config(int seg_cost, int row_cost, int hub_deg, int piece_edges);
-/* tuning knobs of the hot kernel's headline instantiation (fp32 x4, weighted sum); other
- * instantiations ignore them.  rows_in_flight in {4, 8, 16}; variant_bits: 1 = non-temporal
- * stores of Y, 2 = non-temporal index loads, 4 = prefetch of the next index tile, 8 = index tile
- * staged through LDS instead of v_readlane (kept for the record: DESIGN.md §7).  Default 8, 1. */
-int mp_spmm_kernel_config(int rows_in_flight, int variant_bits);
-/* layout experiment only (timing studies; results are wrong for hub rows): read row c of X at
- * X + (c % k) * stride_floats + (c / k) * ldx.  k <= 1 = off (default). */
-int mp_spmm_debug_xregions(int k, int64_t stride_floats);
-int mp_spmm_plan_bytes(int64_t N, int64_t nnz, size_t* bytes_host);
+/* cfg_host: {seg_cost, row_cost, hub_deg, piece_edges} or NULL for the defaults {320, 4, 1024, 256}: a segment is a
+ * run of whole rows of cost ~seg_cost (1 per stored entry + row_cost per row); rows with more than hub_deg entries
+ * are split into pieces of piece_edges.  The configuration travels with the plan (counts_host[5..7]); there is no
+ * process-wide state. */
+int mp_spmm_plan_bytes(int64_t N, int64_t nnz, const int32_t* cfg_host, size_t* bytes_host);
 /* counts_host[8] <- {n_seg, n_hub, n_piece, cap_hub, cap_piece, seg_cost, hub_deg,
  * piece_edges}; SYNCHRONISES `stream` (once per graph) */
-int mp_spmm_plan_build(const int32_t* rowptr, int64_t N, int64_t nnz,
+int mp_spmm_plan_build(const int32_t* rowptr, int64_t N, int64_t nnz, const int32_t* cfg_host,
                        int32_t* plan, size_t plan_bytes, int32_t* counts_host,
                        mp_stream_t stream);
 /* workspace bytes for an aggregation of width d with this plan */
@@ -267,19 +290,25 @@ int mp_bn_train_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t l
  * going through HBM: a workgroup reduces a 32-row tile into LDS and multiplies it by W on the matrix cores
  * while the other workgroups of the compute unit gather.  reduce = MP_SUM | MP_MEAN (mean: rows divided by
  * their entry count, S must be NULL); stored values (val NULL = ones).
- * F must be 64, 128 or 256 and d_out even (MP_ERR_UNSUPPORTED otherwise: use mp_spmm_csr_f32 +
- * mp_dense_fused_f32).  P (optional, [N, F]) receives the aggregated rows (kept for the weight gradient).
- * No plan, no workspace; bitwise reproducible. */
-/* tuning knobs of the kernel below (process-wide): rows in flight per wave (4 | 8), variant bits
- * (1 = non-temporal stores of out; W fragments fetched 6 / 4 / 2 K groups ahead = 2 / 16 / 32, otherwise 1;
- * 64 = 8-byte instead of 16-byte stores of out; 4, 8, 128 and 256 are timing diagnostics — skip the MFMA phase /
- * skip the gather phase / even workgroups gather and odd ones multiply / the MFMA phase keeps W in registers and
- * stores nothing — and produce WRONG results); defaults 8, 32 */
-int mp_fused_config(int rows_in_flight, int variant_bits);
+ * F must be 64, 128, 256 or 512 and d_out even (F = 512: two K halves over the same row tile, d_out <= 512;
+ * MP_ERR_UNSUPPORTED otherwise: use mp_spmm_csr_f32 + mp_dense_fused_f32).  P (optional, [N, F]) receives the
+ * aggregated rows (kept for the weight gradient).  defer_act (optional, [N] uint8): rows with a nonzero flag are
+ * stored WITHOUT the activation (mp_id_fixup_f32 finishes them).  A sign-bit identity mark on col
+ * (mp_mark_id_sources) is ignored.  No plan, no workspace, no process-wide state; bitwise reproducible. */
 int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
                      const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale, const float* W,
-                     int64_t ldw, int32_t d_out, const float* bias, int act, float* P, int64_t ldp, float* out,
-                     int64_t ldo, mp_stream_t stream);
+                     int64_t ldw, int32_t d_out, const float* bias, int act, const uint8_t* defer_act, float* P,
+                     int64_t ldp, float* out, int64_t ldo, mp_stream_t stream);
+
+/* The identity branch of the ID layers on top of mp_agg_dense_f32: out = act(A (X W + S X W_id) + b)
+ * (gcn_id, TfgIDLayer.py:510-523; GCNIDConvLayer.forward, idconv.py:150-177) equals
+ * act((A X) W + b + A_id Z) with Z = X[id] W_id (n_id rows: a small product the caller makes) and A_id the stored
+ * entries whose source is an identity node.  mp_agg_dense_f32 is run with defer_act[r] != 0 on the rows that own
+ * such an entry (they are stored without the activation), then this call finishes exactly those rows:
+ *   out[rows[k], :] = act(out[rows[k], :] + sum_{e in [crp[k], crp[k+1])} val[e] * Z[slot[e], :])
+ * rows [n_rows] ascending row ids, crp [n_rows + 1], slot [crp[n_rows]] = row of Z, val NULL = ones. */
+int mp_id_fixup_f32(const int32_t* rows, const int32_t* crp, const int32_t* slot, const float* val, int64_t n_rows,
+                    const float* Z, int64_t ldz, float* out, int64_t ldo, int32_t d, int act, mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * Dense transform after the aggregation, fused (K10 / K11 / K15):       *
@@ -292,8 +321,6 @@ int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val
  * idconv.py:152-184).  Any F, d and leading dimensions; 16-byte loads  *
  * when F % 8 == 0, d % 4 == 0 and rows are 16-byte aligned.             *
  * ------------------------------------------------------------------ */
-/* tuning knob: 0 / 2 = 128-column block tile (default), 4 = 256-column tile when d > 128 */
-int mp_dense_config(int force_tn);
 int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W,
                        const float* Q, int64_t ldq, const float* W_id,
                        const float* bias, int act, float* out, int64_t ldo,

@@ -26,8 +26,10 @@ class SparseAdj:
         # sparse_adj.py:18-48
         self.edge_index = edge_index.to(torch.int64)
         if edge_weight is None:
-            edge_weight = torch.ones(self.edge_index.size(1), dtype=torch.float32)
-        self.edge_weight = edge_weight.to(torch.float32)
+            edge_weight = torch.ones(self.edge_index.size(1), dtype=torch.get_default_dtype())
+        # float32 as in the reference (sparse_adj.py:31-36 casts to tf.float32); the tests' float64 evaluation of
+        # the same formulas runs under torch.set_default_dtype(torch.float64)
+        self.edge_weight = edge_weight.to(torch.get_default_dtype())
         if shape is None:
             n = int(self.edge_index.max()) + 1 if self.edge_index.numel() else 0
             shape = [n, n]
@@ -60,7 +62,7 @@ class SparseAdj:
     def reduce_sum(self, axis=-1):
         # sparse_adj.py:84-85: unsorted_segment_sum(edge_weight, index, num)
         ra = self._reduce_index(axis)
-        out = torch.zeros(self.shape[ra], dtype=torch.float32)
+        out = torch.zeros(self.shape[ra], dtype=self.edge_weight.dtype)
         return out.index_add_(0, self.edge_index[ra], self.edge_weight)
 
     def matmul(self, h):
@@ -204,7 +206,7 @@ def pyg_gcn_norm(edge_index, num_nodes, edge_weight=None, improved=False):
     """GCNIDConvLayer.norm / GeneralIDConvLayer.norm / GeneralConvLayer.norm
     (idconv.py:44-60,132-148; generalconv.py:44-60): degree scattered on edge_index[0]"""
     if edge_weight is None:
-        edge_weight = torch.ones(edge_index.size(1), dtype=torch.float32)
+        edge_weight = torch.ones(edge_index.size(1), dtype=torch.get_default_dtype())
     fill_value = 1.0 if not improved else 2.0
     edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, fill_value, num_nodes)
     row, col = edge_index[0], edge_index[1]

@@ -17,10 +17,6 @@ for M in (1_000_000, 10_000_000):
         P = torch.rand(M, F, device=dev) - 0.5; Q = torch.rand(M, F, device=dev) - 0.5
         W = torch.rand(F, d, device=dev) - 0.5; Wi = torch.rand(F, d, device=dev) - 0.5; b = torch.rand(d, device=dev)
         t_single_lib = tm(lambda: torch.relu(torch.addmm(b, P, W)))
-        _lib.lib().mp_dense_config(4)
-        t_single_tn2 = tm(lambda: ops._raw_dense_fused(P, W, None, None, b, True))
-        t_dual_tn2 = tm(lambda: ops._raw_dense_fused(P, W, Q, Wi, b, True))
-        _lib.lib().mp_dense_config(0)
         t_single = tm(lambda: ops._raw_dense_fused(P, W, None, None, b, True))
         t_dual_lib = tm(lambda: torch.relu(P @ W + Q @ Wi + b))
         t_dual = tm(lambda: ops._raw_dense_fused(P, W, Q, Wi, b, True))
@@ -30,6 +26,6 @@ for M in (1_000_000, 10_000_000):
         del g
         fl = 2.0 * M * F * d
         print(f"M={M} F={F} d={d}: single lib {t_single_lib:7.2f} ms ({fl/t_single_lib/1e9:6.1f} TF) fused {t_single:7.2f} ms ({fl/t_single/1e9:6.1f} TF) | "
-              f"dual lib {t_dual_lib:7.2f} ms fused {t_dual:7.2f} ms ({2*fl/t_dual/1e9:6.1f} TF) | 256-col tile: single {t_single_tn2:7.2f} dual {t_dual_tn2:7.2f} | wgrad P^T g: lib {t_wg_lib:7.2f} ms engine {t_wg:7.2f} ms ({fl/t_wg/1e9:6.1f} TF)", flush=True)
+              f"dual lib {t_dual_lib:7.2f} ms fused {t_dual:7.2f} ms ({2*fl/t_dual/1e9:6.1f} TF) | wgrad P^T g: lib {t_wg_lib:7.2f} ms engine {t_wg:7.2f} ms ({fl/t_wg/1e9:6.1f} TF)", flush=True)
         del P, Q
         torch.cuda.empty_cache()

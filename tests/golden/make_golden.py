@@ -138,6 +138,26 @@ def gen_layers():
         for (pn, p), g in zip(params.items(), grads[1:]):
             rec[f"{key}/param/{pn}"] = p.detach().numpy()
             rec[f"{key}/grad/{pn}"] = (torch.zeros_like(p) if g is None else g).numpy()
+        # the same record evaluated in float64 (same fp32 inputs and weights, exact arithmetic for this purpose):
+        # the tests hold the engine to 1e-5 of THIS, or to twice the fp32 oracle's own distance from it where the
+        # GEMMs' fp32 rounding exceeds 1e-5
+        saved = [p.data for p in params.values()]
+        torch.set_default_dtype(torch.float64)
+        try:
+            for p in params.values():
+                p.data = p.data.double()
+            x = x0.double().requires_grad_(True)
+            out = fn(x)
+            grads = torch.autograd.grad(out, [x] + list(params.values()), grad_outputs=dy[:, :out.size(1)].double(),
+                                        allow_unused=True)
+            rec[f"{key}/out64"] = out.detach().numpy()
+            rec[f"{key}/grad_x64"] = grads[0].numpy()
+            for (pn, p), g in zip(params.items(), grads[1:]):
+                rec[f"{key}/grad64/{pn}"] = (torch.zeros_like(p) if g is None else g).numpy()
+        finally:
+            torch.set_default_dtype(torch.float32)
+            for p, d in zip(params.values(), saved):
+                p.data = d
 
     b = lambda: (torch.randn(D, generator=gen) * 0.1).requires_grad_(True)
     # ---- PyG family ----

@@ -49,16 +49,17 @@ def test_version_and_status_strings():
 def test_argument_validation_without_device():
     lib = _lib.lib()
     nb = C.c_size_t(0)
-    assert lib.mp_spmm_plan_bytes(-1, 0, C.byref(nb)) == 1
-    assert lib.mp_spmm_plan_bytes(10, 2**31, C.byref(nb)) == 2          # int32 index limit
-    assert lib.mp_spmm_plan_bytes(1000, 10000, C.byref(nb)) == 0 and nb.value > 0
+    assert lib.mp_spmm_plan_bytes(-1, 0, None, C.byref(nb)) == 1
+    assert lib.mp_spmm_plan_bytes(10, 2**31, None, C.byref(nb)) == 2          # int32 index limit
+    assert lib.mp_spmm_plan_bytes(1000, 10000, None, C.byref(nb)) == 0 and nb.value > 0
+    default_bytes = nb.value
+    assert lib.mp_spmm_plan_bytes(1000, 10000, (C.c_int32 * 4)(32, 4, 1024, 256), C.byref(nb)) == 1   # seg_cost too small
+    assert lib.mp_spmm_plan_bytes(1000, 10000, (C.c_int32 * 4)(64, 1, 64, 64), C.byref(nb)) == 0 and nb.value > default_bytes
     counts = (C.c_int32 * 8)(10, 0, 3, 1, 4, 320, 1024, 256)
     assert lib.mp_spmm_ws_bytes(counts, 256, 0, 0, C.byref(nb)) == 0
     assert nb.value >= 3 * 256 * 4
     assert lib.mp_spmm_ws_bytes(counts, 256, 2, 0, C.byref(nb)) == 0    # max: values + argmax
     assert nb.value >= 2 * 3 * 256 * 4
-    assert lib.mp_spmm_plan_config(32, 4, 1024, 256) == 1               # seg_cost too small
-    assert lib.mp_spmm_plan_config(320, 4, 1024, 256) == 0
     # null pointers are rejected before any launch
     assert lib.mp_spmm_csr_f32(None, None, None, 5, None, counts, None, 4, None, 4, 4, 0, None, 0, 0.0,
                                None, 0, None, None, 0, None) == 1

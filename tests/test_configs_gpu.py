@@ -1,0 +1,319 @@
+"""Every configuration BASELINE.json names, exercised on the GPU against the oracle.
+
+    C1  gcnconv_tf, 16-graph batch of 64-node scale-free graphs, 3 layers, d = 64          (model level)
+    C3  idgcn_tf (ID-GNN Full, ego nets): Cora-like (N = 2708, F = 1433, radius 2) and
+        ENZYMES-like (small graphs, radius 3), d = 128                                      (model level)
+    C4  ginconv_tf / sageconv_tf operators at N = 10^7, d = 256                             (properties + sampled rows)
+    C5  idgin_tf / two-branch operators at N = 10^7, d = 512                                (properties + sampled rows)
+(C2, gcnconv_tf at 10^6 / d = 256, is test_parity_gpu.py::test_full_size_properties_c2_and_c4.)
+
+Cora and ENZYMES are not available offline: the stand-ins have their shapes (node / edge /
+feature / class counts, sparse bag-of-words density; small dense graphs).  The oracle (oracle/ref_layers.py,
+parity unpinned — DESIGN.md §3) is evaluated twice, in float32 as the reference runs and in float64;
+tests/_tol.py states the bar: 1e-5 of every output row's own magnitude against the float64 evaluation, or twice the
+float32 oracle's own distance from it.
+"""
+import networkx as nx
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _tol import assert_close_all, assert_close_rows
+from oracle import ref_layers as RL
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _directed(G):
+    e = np.array(list(G.edges()), dtype=np.int64).reshape(-1, 2)
+    return np.ascontiguousarray(np.concatenate([e, e[:, ::-1]], axis=0).T)
+
+
+def _cc_labels(G, nodes, classes):
+    cc = torch.tensor([nx.clustering(G, i) for i in nodes], dtype=torch.float32)
+    edges = torch.quantile(cc, torch.linspace(0, 1, classes + 1)[1:-1])
+    return torch.bucketize(cc, edges)           # "balanced" bins of the clustering coefficient (feature_augment.py:218-231)
+
+
+def _oracle_tfg_gcn_model(params, x, ei, ids, label_index, labels, dtype):
+    """main_zd.py:28-74 (three GCN / IDGCN layers -> Flatten -> Dense(256, relu) -> Dense(num_labels)) with the loss
+    of graphgym/loss.py:53-68, on the CPU in `dtype`"""
+    torch.set_default_dtype(dtype)
+    try:
+        P = {k: v.detach().cpu().to(dtype).clone().requires_grad_(True) for k, v in params.items()}
+        h = x.detach().cpu().to(dtype)
+        for i in range(3):
+            h = RL.gcn_id(h, ei, ids, None, P[f"convs.{i}.kernel"], P.get(f"convs.{i}.kernel_id"),
+                          P[f"convs.{i}.bias"], "relu")
+        logits = torch.relu(h @ P["mlp.1.weight"].t() + P["mlp.1.bias"]) @ P["mlp.3.weight"].t() + P["mlp.3.bias"]
+        ce = F.cross_entropy(logits[label_index], labels)
+        kern = [P[k] for k in P if k.endswith("kernel") or k.endswith("kernel_id") or k.endswith(".weight")]
+        loss = ce + 5e-4 * sum((p * p).sum() / 2 for p in kern)
+        loss.backward()
+        return logits.detach(), loss.detach(), {k: v.grad for k, v in P.items()}
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def _check_model_against_oracle(dev, kind, x, ei, ids, label_index, labels, f_in, d, classes, seed):
+    from graphgym_amd import harness as H
+    torch.manual_seed(seed)
+    model = H.TfgNodeModel(kind, f_in, d, classes).to(dev)
+    batch = H.Batch()
+    inputs = [x.to(dev), ei.to(dev)] + ([ids.to(dev)] if model.with_id else [])
+    logits = model(inputs, holder=batch)
+    loss = H.tfg_loss(logits, label_index.to(dev), labels.to(dev), model.kernel_parameters())
+    loss.backward()
+    params = dict(model.named_parameters())
+    oid = ids if model.with_id else None
+    l64, loss64, g64 = _oracle_tfg_gcn_model(params, x, ei, oid, label_index, labels, torch.float64)
+    l32, loss32, g32 = _oracle_tfg_gcn_model(params, x, ei, oid, label_index, labels, torch.float32)
+    assert_close_rows(logits, l64, 1e-5, ref32=l32, what=f"{kind} logits")
+    assert_close_all(loss.reshape(1), loss64.reshape(1), 1e-5, ref32=loss32.reshape(1), what=f"{kind} loss")
+    for k, p in params.items():
+        assert p.grad is not None, k
+        assert_close_all(p.grad, g64[k], 1e-5, ref32=g32[k], what=f"{kind} grad {k}")
+
+
+# ------------------------------------------------------------------------------------------ C1
+def test_c1_gcnconv_tf_batch_of_16_scalefree_graphs(dev):
+    """config C1: a batch of 16 graphs of the shape of run/datasets/scalefree.pkl (64 nodes, mean degree ~7.8,
+    node_feature = [1.]), 3-layer Tfg-gcnconv, d = 64: logits, loss and every parameter gradient"""
+    graphs = [nx.powerlaw_cluster_graph(64, 4, 0.3, seed=100 + s) for s in range(16)]
+    U = nx.disjoint_union_all(graphs)
+    n = U.number_of_nodes()
+    assert n == 1024
+    ei = torch.from_numpy(_directed(U))
+    x = torch.ones(n, 1)
+    classes = 10
+    labels = _cc_labels(U, range(n), classes)
+    idx = torch.arange(n)
+    _check_model_against_oracle(dev, "gcn", x, ei, idx[:0], idx, labels, 1, 64, classes, seed=1)
+
+
+# ------------------------------------------------------------------------------------------ C3
+def _ego_batch(dev, G, n, centres, radius):
+    import graphgym_amd as ga
+    from graphgym_amd.ego import ego_batch
+    base = ga.CSRGraph.from_edge_index(torch.from_numpy(_directed(G)).to(dev), n, validate=True)
+    ei, orig, ids, ego_of = ego_batch(base, centres.to(dev), radius)
+    # the batcher against networkx on THIS graph: sizes of every ego and of its induced edge set
+    # (graphgym/models/transform.py:24-36; the relabelling inside an ego is covered by tests/test_ego_gpu.py)
+    sizes = np.bincount(ego_of.cpu().numpy(), minlength=centres.numel())
+    edges = np.bincount(ego_of.cpu().numpy()[ei[0].cpu().numpy()], minlength=centres.numel())
+    for k in np.random.RandomState(0).choice(centres.numel(), size=min(24, centres.numel()), replace=False):
+        eg = nx.ego_graph(G, int(centres[k]), radius=radius)
+        assert sizes[k] == eg.number_of_nodes(), k
+        assert edges[k] == 2 * eg.number_of_edges() - nx.number_of_selfloops(eg), k
+    return ei.cpu(), orig.cpu(), ids.cpu()
+
+
+def test_c3_idgcn_tf_cora_like_ego_batch(dev):
+    """config C3 (Cora stand-in): N = 2708, 10556 directed edges, F = 1433 sparse bag-of-words, 7 classes; ID-GCN Full
+    (three IDGCN layers, d = 128) on a batch of 128 radius-2 ego nets built by the GPU batcher"""
+    n, f_in, classes = 2708, 1433, 7
+    G = nx.gnm_random_graph(n, 5278, seed=3)
+    gen = torch.Generator().manual_seed(0)
+    feats = (torch.rand(n, f_in, generator=gen) < 0.0127).float()
+    labels_all = torch.randint(0, classes, (n,), generator=gen)
+    cen = torch.randperm(n, generator=gen)[:128]
+    ei, orig, ids = _ego_batch(dev, G, n, cen, 2)
+    x = feats[orig]
+    _check_model_against_oracle(dev, "idgcn", x, ei, ids, ids, labels_all[cen], f_in, 128, classes, seed=2)
+
+
+def test_c3_idgcn_tf_enzymes_like_ego_batch(dev):
+    """config C3 (ENZYMES stand-in): 16 small graphs with >= 200 directed edges each (loader.py:45-53), 3 one-hot
+    node features, clustering-coefficient labels, every node a centre, radius 3, d = 128"""
+    rs = np.random.RandomState(7)
+    graphs = []
+    for s in range(16):
+        k = int(rs.randint(28, 56))
+        graphs.append(nx.gnm_random_graph(k, int(rs.randint(100, 140)), seed=50 + s))
+    U = nx.disjoint_union_all(graphs)
+    n = U.number_of_nodes()
+    gen = torch.Generator().manual_seed(1)
+    feats = F.one_hot(torch.randint(0, 3, (n,), generator=gen), 3).float()
+    classes = 6
+    labels_all = _cc_labels(U, range(n), classes)
+    cen = torch.arange(n)
+    ei, orig, ids = _ego_batch(dev, U, n, cen, 3)
+    x = feats[orig]
+    _check_model_against_oracle(dev, "idgcn", x, ei, ids, ids, labels_all, 3, 128, classes, seed=3)
+
+
+# ------------------------------------------------------------------------------------------ C4 / C5
+N_BIG = 10_000_000
+
+
+@pytest.fixture(scope="module")
+def big_graph(dev):
+    """BA(10^7, 5), symmetrised and deduplicated, unweighted, no loops: the operator of the GIN /
+    SAGE layers; cached for the module"""
+    import graphgym_amd as ga
+    from graphgym_amd import graphgen
+    ei = graphgen.ba_edge_index(N_BIG, 5, seed=12345, device=dev)
+    G = ga.CSRGraph.from_edge_index(ei, N_BIG)
+    del ei
+    torch.cuda.empty_cache()
+    yield G
+    del G
+    torch.cuda.empty_cache()
+
+
+def _sample_rows(G, gen, k=512):
+    rows = torch.randint(0, G.num_nodes, (k,), device=G.device, generator=gen)
+    return torch.cat([torch.arange(0, 8, device=G.device), rows])          # the hubs too (BA: oldest nodes)
+
+
+def _sampled_entries(G, rows):
+    """(segment id, column, value) of every stored entry of the sampled rows, on the CPU"""
+    rp = G.rowptr.long()
+    start, stop = rp[rows], rp[rows + 1]
+    deg = stop - start
+    seg = torch.repeat_interleave(torch.arange(rows.numel(), device=G.device), deg)
+    base = torch.cumsum(deg, 0) - deg
+    pos = torch.arange(int(deg.sum()), device=G.device) - base[seg] + start[seg]
+    col = G.col[pos].long()
+    val = None if G.val is None else G.val[pos]
+    return seg.cpu(), col, (None if val is None else val.cpu()), deg.cpu()
+
+
+def _sampled_aggregate(G, x, rows, reduce="sum"):
+    """the oracle (oracle/ref_ops.coo_aggregate: gather -> scale -> index_add_) on the sampled rows' entries, in
+    float32 as the reference runs and in float64: ([R, d] float64, [R, d] float32), CPU"""
+    seg, col, val, deg = _sampled_entries(G, rows)
+    xg = x[col].cpu()
+    colz = torch.arange(seg.numel())
+    r32 = R.coo_aggregate(seg, colz, val, xg, rows.numel(), reduce)
+    r64 = R.coo_aggregate(seg, colz, None if val is None else val.double(), xg.double(), rows.numel(), reduce)
+    return r64, r32, deg
+
+
+def _colsum_check(G, x, y, what, self_scale=0.0):
+    """checksum of checksums in float64: sum_i y[i, :] == sum_j (column sum of the operator at j + self_scale) * x[j, :],
+    accumulated in row chunks so nothing of size [N, d] float64 is materialised"""
+    n, d = x.shape
+    csum = G.degree("col").double() + self_scale
+    lhs = torch.zeros(d, dtype=torch.float64, device=x.device)
+    rhs = torch.zeros(d, dtype=torch.float64, device=x.device)
+    step = 1 << 20
+    for s in range(0, n, step):
+        lhs += y[s:s + step].double().sum(0)
+        rhs += (csum[s:s + step, None] * x[s:s + step].double()).sum(0)
+    assert float((lhs - rhs).abs().max()) <= 1e-6 * float(rhs.abs().max() + n ** 0.5), what
+
+
+def test_c4_gin_combine_and_mean_at_10m(dev, big_graph):
+    """config C4 operators at full size: the GIN combine (1 + eps) x + sum_j x_j (unweighted sum with the self term
+    in the epilogue, TfgIDLayer.py:157-159) and the SAGE neighbour mean (TfgIDLayer.py:92-98), d = 256"""
+    from graphgym_amd import ops
+    G, n, d = big_graph, N_BIG, 256
+    gen = torch.Generator(device=dev).manual_seed(7)
+    ones = torch.ones(n, d, device=dev)
+    cnt = G.entry_counts()
+    y = ops.spmm(G, ones, "sum", self_scale=1.0)
+    assert torch.equal(y[:, 0], cnt + 1.0)                       # integers: exact
+    assert float((y - y[:, :1]).abs().max()) == 0.0
+    m = ops.spmm(G, ones, "mean")
+    assert torch.equal(m[:, 0], (cnt > 0).float())               # mean of ones = 1, empty rows = 0
+    del ones, y, m
+    x = torch.rand(n, d, device=dev, generator=gen) * 2 - 1
+    rows = _sample_rows(G, gen)
+    # GIN combine
+    y = ops.spmm(G, x, "sum", self_scale=1.0)
+    r64, r32, _ = _sampled_aggregate(G, x, rows, "sum")
+    xs = x[rows].cpu()
+    assert_close_rows(y[rows], r64 + xs.double(), 1e-5, ref32=r32 + xs, what="C4 (1+eps)x + sum")
+    _colsum_check(G, x, y, "C4 gin combine checksum", self_scale=1.0)
+    y3 = ops.spmm(G, x * 3.0, "sum", self_scale=1.0)
+    assert float((y3 - 3.0 * y).abs().max()) <= 1e-5 * float(y.abs().max())      # linearity
+    del y3, y
+    # mean, forward and its backward (the transposed operator with 1 / count weights)
+    xg = x.clone().requires_grad_(True)
+    m = ops.spmm(G, xg, "mean")
+    r64, r32, _ = _sampled_aggregate(G, x, rows, "mean")
+    assert_close_rows(m[rows], r64, 1e-5, ref32=r32, what="C4 mean")
+    dy = torch.rand(n, d, device=dev, generator=gen) - 0.5
+    m.backward(dy)
+    # dX[j] = sum_{i : j in N(i)} dy[i] / count(i): the graph is symmetric, so row j of the operator lists those i
+    inv = 1.0 / G.entry_counts().clamp(min=1.0)
+    seg, col, _, _ = _sampled_entries(G, rows)
+    contrib = (dy[col] * inv[col, None]).cpu()
+    g32 = torch.zeros(rows.numel(), d).index_add_(0, seg, contrib)
+    g64 = torch.zeros(rows.numel(), d, dtype=torch.float64).index_add_(0, seg, contrib.double())
+    assert_close_rows(xg.grad[rows], g64, 1e-5, ref32=g32, what="C4 mean backward")
+
+
+def test_c4_sage_concat_and_fused_mlp_head_at_10m(dev, big_graph):
+    """config C4 layers at full size: MeanGraphSage's [x W_s || mean W_n] + b -> relu (TfgIDLayer.py:100-117) and GIN's
+    combine -> first Dense(relu) as ONE kernel (main_zd.py:181-186), d = 256, sampled rows against float64"""
+    from graphgym_amd import ops
+    G, n, d = big_graph, N_BIG, 256
+    gen = torch.Generator(device=dev).manual_seed(11)
+    x = torch.rand(n, d, device=dev, generator=gen) * 2 - 1
+    rows = _sample_rows(G, gen)
+    Ws = (torch.rand(d, d // 2, device=dev, generator=gen) - 0.5) * (2.0 / d ** 0.5)
+    Wn = (torch.rand(d, d // 2, device=dev, generator=gen) - 0.5) * (2.0 / d ** 0.5)
+    W = (torch.rand(d, d, device=dev, generator=gen) - 0.5) * (2.0 / d ** 0.5)
+    b = torch.rand(d, device=dev, generator=gen) - 0.5
+    xs = x[rows].cpu()
+    m64, m32, _ = _sampled_aggregate(G, x, rows, "mean")
+    s64, s32, _ = _sampled_aggregate(G, x, rows, "sum")
+
+    with torch.no_grad():
+        out = ops.sage_concat(G, x, Ws, Wn, b, relu=True)
+    ref64 = torch.relu(torch.cat([xs.double() @ Ws.cpu().double(), m64 @ Wn.cpu().double()], 1) + b.cpu().double())
+    ref32 = torch.relu(torch.cat([xs @ Ws.cpu(), m32 @ Wn.cpu()], 1) + b.cpu())
+    assert_close_rows(out[rows], ref64, 1e-5, ref32=ref32, what="C4 sage_concat")
+    del out
+
+    assert ops.agg_dense_supported(G, x, W)
+    with torch.no_grad():
+        out = ops.agg_dense(G, x, W, bias=b, relu=True, self_scale=1.0)
+    ref64 = torch.relu((s64 + xs.double()) @ W.cpu().double() + b.cpu().double())
+    ref32 = torch.relu((s32 + xs) @ W.cpu() + b.cpu())
+    assert_close_rows(out[rows], ref64, 1e-5, ref32=ref32, what="C4 fused GIN head")
+
+
+def test_c5_d512_aggregation_and_two_branch_at_10m(dev, big_graph):
+    """config C5 operators at full size, d = 512: the GCN-normalised weighted sum, the GIN combine, and the ID-GNN
+    two-branch aggregation (P = A x, Q = A S x in one pass, TfgIDLayer.py:510-517) with 1 % identity nodes"""
+    from graphgym_amd import ops
+    G0, n, d = big_graph, N_BIG, 512
+    gen = torch.Generator(device=dev).manual_seed(13)
+    x = torch.rand(n, d, device=dev, generator=gen) * 2 - 1
+    rows = _sample_rows(G0, gen)
+    # GIN combine at d = 512 (idgin_tf's aggregation, TfgIDLayer.py:157-159)
+    y = ops.spmm(G0, x, "sum", self_scale=1.0)
+    r64, r32, _ = _sampled_aggregate(G0, x, rows, "sum")
+    xs = x[rows].cpu()
+    assert_close_rows(y[rows], r64 + xs.double(), 1e-5, ref32=r32 + xs, what="C5 (1+eps)x + sum, d=512")
+    _colsum_check(G0, x, y, "C5 gin combine checksum", self_scale=1.0)
+    del y
+    # weighted (GCN-normalised, loops removed-and-added as GCNIDConvLayer does) sum and the two-branch form
+    G = G0.gcn_norm("row")
+    ids = torch.randperm(n, device=dev, generator=gen)[: n // 100]
+    ids = torch.cat([torch.arange(0, 4, device=dev), ids[ids >= 4]])        # a few hubs among the identity nodes
+    P, Q = ops.idgnn_aggregate(G, ids, x)
+    y = ops.spmm(G, x, "sum")
+    assert torch.equal(P, y)                                     # the first branch IS the plain aggregation
+    r64, r32, _ = _sampled_aggregate(G, x, rows, "sum")
+    assert_close_rows(y[rows], r64, 1e-5, ref32=r32, what="C5 weighted sum, d=512")
+    del y, P
+    xm = torch.zeros_like(x)
+    xm[ids] = x[ids]
+    yq = ops.spmm(G, xm, "sum")                                  # A (S x) by the plain kernel
+    assert torch.equal(Q, yq)
+    is_id = torch.zeros(n, dtype=torch.bool, device=dev)
+    is_id[ids] = True
+    seg, col, val, _ = _sampled_entries(G, rows)
+    keep = is_id[col].cpu()
+    xg = x[col].cpu()
+    q64 = torch.zeros(rows.numel(), d, dtype=torch.float64).index_add_(
+        0, seg[keep], val[keep, None].double() * xg[keep].double())
+    q32 = torch.zeros(rows.numel(), d).index_add_(0, seg[keep], val[keep, None] * xg[keep])
+    assert_close_rows(Q[rows], q64, 1e-5, ref32=q32, what="C5 identity branch Q, d=512")
+    assert int((Q[rows].abs().sum(1) > 0).sum()) > 0             # the sample does touch identity neighbours

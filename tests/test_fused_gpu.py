@@ -36,6 +36,9 @@ def make_graph(n, E, seed, hubs=False, weighted=True):
     (3333, 40000, 256, 130, True, True, 0.0),
     (64, 64, 256, 512, False, False, 2.0),
     (33, 0 + 1, 64, 2, True, False, 0.0),
+    (700, 9000, 512, 512, True, False, 1.0),      # config C5's width: two K halves over the row tile
+    (1500, 20000, 512, 130, False, True, 0.0),
+    (90, 500, 512, 256, True, False, 0.0),
 ])
 def test_agg_dense_matches_oracle(dev, n, E, F, d, weighted, hubs, self_scale):
     import graphgym_amd as ga
@@ -91,7 +94,7 @@ def test_agg_dense_falls_back_outside_its_shapes(dev):
     from graphgym_amd._lib import lib, ptr
     x, W, out = torch.randn(n, 48, device=dev), torch.randn(48, 32, device=dev), torch.empty(n, 32, device=dev)
     st = lib().mp_agg_dense_f32(ptr(G.rowptr), ptr(G.col), ptr(G.val), n, 0, ptr(x), 48, 48, None, 0, 0.0, ptr(W), 32,
-                                32, None, 0, None, 0, ptr(out), 32, None)
+                                32, None, 0, None, None, 0, ptr(out), 32, None)
     assert st == 2                                                # MP_ERR_UNSUPPORTED
 
 
@@ -259,27 +262,96 @@ def test_star_hub_goes_to_the_plan_based_kernel(dev):
     close(out[n - 1], ref_leaf.float())
 
 
-def test_tuning_variants_are_numerically_identical(dev):
-    """mp_fused_config knobs (rows in flight, W prefetch depth, store width / non-temporal stores) change the
-    schedule, not the arithmetic: bitwise the same output as the default configuration"""
+@pytest.mark.parametrize("n,E,F,d,weighted,hubs,n_id,self_scale", [
+    (1200, 15000, 256, 256, True, False, 40, 0.0),
+    (2049, 30000, 128, 64, True, True, 300, 0.0),
+    (500, 4000, 64, 130, False, False, 1, 0.0),
+    (800, 9000, 512, 512, True, False, 64, 0.0),
+    (300, 2500, 256, 256, True, False, 300, 0.5),       # every node an identity node
+])
+def test_agg_dense_id_matches_oracle(dev, n, E, F, d, weighted, hubs, n_id, self_scale):
+    """out = act(A (x W + S x W_id) + b) (gcn_id, TfgIDLayer.py:510-523; idconv.py:150-177) through the one-kernel layer
+    plus the identity fix-up, forward and every gradient, against a float64 evaluation of the reference's own order
+    (transform, scatter-add the identity rows, aggregate)"""
     import graphgym_amd as ga
     from graphgym_amd import ops
-    from graphgym_amd._lib import lib
-    n, F = 4000, 256
-    ei, w = make_graph(n, 60000, seed=21, hubs=True)
-    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, w.to(dev), dst_row=0)
-    gen = torch.Generator().manual_seed(5)
-    x = torch.randn(n, F, generator=gen).to(dev)
-    W = (torch.randn(F, F, generator=gen) / 16).to(dev)
-    b = torch.randn(F, generator=gen).to(dev)
-    L = lib()
+    ei, w = make_graph(n, E, seed=n + F + 1, hubs=hubs, weighted=weighted)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(n, F, generator=gen)
+    W = torch.randn(F, d, generator=gen) / F ** 0.5
+    Wid = torch.randn(F, d, generator=gen) / F ** 0.5
+    b = torch.randn(d, generator=gen)
+    ids = torch.randperm(n, generator=gen)[:n_id]
+    if hubs and 5 not in ids.tolist():
+        ids[0] = 5                                                  # a hub row's own node among the identity nodes
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, None if w is None else w.to(dev), dst_row=0)
+    for relu in (False, True):
+        xr, Wr, Wir, br = (t.clone().double().requires_grad_(True) for t in (x, W, Wid, b))
+        h = xr @ Wr
+        h = h.index_add(0, ids, xr[ids] @ Wir)                     # TfgIDLayer.py:513-515
+        agg = torch.zeros(n, d, dtype=torch.float64).index_add_(
+            0, ei[0], h[ei[1]] * (w.double().unsqueeze(1) if w is not None else 1.0))
+        ref = agg + self_scale * (xr @ Wr) + br
+        ref = torch.relu(ref) if relu else ref
+        up = torch.randn(n, d, generator=gen)
+        ref.backward(up.double())
+        xd, Wd, Wid_d, bd = (t.to(dev).requires_grad_(True) for t in (x, W, Wid, b))
+        out = ops.agg_dense_id(G, xd, Wd, Wid_d, ids.to(dev), bias=bd, relu=relu, self_scale=self_scale)
+        assert out is not None
+        out.backward(up.to(dev))
+        close(out, ref)
+        close(xd.grad, xr.grad)
+        close(Wd.grad, Wr.grad, 2e-5)
+        close(Wid_d.grad, Wir.grad, 2e-5)
+        close(bd.grad, br.grad)
+        out2 = ops.agg_dense_id(G, xd, Wd, Wid_d, ids.to(dev), bias=bd, relu=relu, self_scale=self_scale)
+        assert torch.equal(out, out2)
+    # the two-kernel formulation (two-branch aggregation + dual GEMM) gives the same numbers
+    P, Q = ops.idgnn_aggregate(G, ids.to(dev), x.to(dev))
+    two = ops.dense_fused(P, W.to(dev), Q, Wid.to(dev), b.to(dev)) + self_scale * (x.to(dev) @ W.to(dev))
+    one = ops.agg_dense_id(G, x.to(dev), W.to(dev), Wid.to(dev), ids.to(dev), bias=b.to(dev), self_scale=self_scale)
+    close(one, two)
+    with pytest.raises(ValueError, match="duplicate"):
+        ops.agg_dense_id(G, x.to(dev), W.to(dev), Wid.to(dev), torch.tensor([1, 1], device=dev))
+
+
+def test_id_layers_take_one_launch(dev):
+    """Tfg-idgcn / gcnidconv at equal widths and the ID-GIN head run the one-kernel layer (one mp_agg_dense_f32 launch
+    per forward) and agree with the reference's transform-first order"""
+    from graphgym_amd import layers as L, ops
+    n, F = 600, 128
+    ei, _ = make_graph(n, 6000, seed=8, weighted=False)
+    ei = torch.cat([ei, ei.flip(0)], dim=1).to(dev)
+    x = torch.randn(n, F, generator=torch.Generator().manual_seed(4)).to(dev)
+    ids = torch.arange(0, n, 7, device=dev)
+    calls = []
+    orig = ops._raw_agg_dense
+    def spy(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+    ops._raw_agg_dense = spy
     try:
-        assert L.mp_fused_config(8, 32) == 0
-        base, _ = ops._raw_agg_dense(G, x, W, b, True)
-        for u, var in ((8, 0), (8, 1), (8, 16), (8, 2), (8, 33), (8, 96), (4, 32), (16, 32)):
-            assert L.mp_fused_config(u, var) == 0
-            out, _ = ops._raw_agg_dense(G, x, W, b, True)
-            assert torch.equal(out, base), (u, var)
-        assert L.mp_fused_config(3, 0) == 1 and L.mp_fused_config(8, 4096) == 1      # MP_ERR_INVALID_ARG
+        torch.manual_seed(0)
+        for make in (lambda order: L.IDGCN(F, activation=torch.relu, in_features=F, order=order),
+                     lambda order: L.GCNIDConvLayer(F, F, bias=True, order=order)):
+            fused, two = make("auto"), make("transform_first")
+            two.load_state_dict(fused.state_dict())
+            fused, two = fused.to(dev), two.to(dev)
+            calls.clear()
+            with torch.no_grad():
+                a = fused([x, ei, ids]) if isinstance(fused, L.IDGCN) else fused(x, ei, ids)
+                assert len(calls) == 1
+                b = two([x, ei, ids]) if isinstance(two, L.IDGCN) else two(x, ei, ids)
+                assert len(calls) == 1
+            close(a, b)
+        gin = L.GINIDConvLayer(L._mlp2(F, F), L._mlp2(F, F)).to(dev)
+        calls.clear()
+        with torch.no_grad():
+            a = gin(x, ei, ids)
+            assert len(calls) == 1
+            g = L.get_graph(None, ei, n, loops="remove")
+            h = ops.spmm(g, x, "sum", self_scale=1.0)
+            b = ops.index_add_rows(gin.nn(h), ids, gin.nn_id(h[ids]))
+        close(a, b)
     finally:
-        L.mp_fused_config(8, 32)
+        ops._raw_agg_dense = orig
