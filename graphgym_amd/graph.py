@@ -9,6 +9,8 @@ idconv.py:165-173 with cached=False).
 Row r holds the in-edges of destination r; ``col`` holds source ids.
 """
 import ctypes as C
+import itertools
+import weakref
 
 import torch
 
@@ -25,6 +27,18 @@ def _require_hip(t, name):
         raise _lib.EngineError(
             f"{name} must live on a HIP device: the engine has no CPU path "
             "(the CPU oracle is test infrastructure only)")
+
+
+_HANDLES = weakref.WeakValueDictionary()     # int handle -> CSRGraph: how a graph crosses the torch.ops.mp.* boundary
+_next_handle = itertools.count(1)
+
+
+def from_handle(h):
+    """the CSRGraph behind a handle passed to a torch.ops.mp.* operator"""
+    try:
+        return _HANDLES[int(h)]
+    except KeyError:
+        raise _lib.EngineError(f"graph handle {h} is not alive (the CSRGraph was garbage-collected)") from None
 
 
 class CSRGraph:
@@ -141,6 +155,21 @@ class CSRGraph:
     @property
     def device(self):
         return self.rowptr.device
+
+    @property
+    def handle(self):
+        """an int naming this graph in torch.ops.mp.* calls (custom ops take tensors and scalars only); the
+        registry holds weak references, the autograd context of an op keeps the graph itself"""
+        h = self.__dict__.get("_handle")
+        if h is None:
+            h = next(_next_handle)
+            self.__dict__["_handle"] = h
+            _HANDLES[h] = self
+        return h
+
+    def variant(self, which):
+        """0: this operator; 1: its transpose; 2: the transposed mean operator (backward of reduce='mean')"""
+        return self if which == 0 else (self.transpose() if which == 1 else self.transpose_mean())
 
     # ---- plan --------------------------------------------------------------
     # segmentation tunables {seg_cost, row_cost, hub_deg, piece_edges} handed to mp_spmm_plan_build per call

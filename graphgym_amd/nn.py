@@ -7,59 +7,109 @@ training mode the statistics, the normalisation, the optional ReLU and the whole
 HBM-bound passes; torch's own kernel needs 0.5 s per backward call on a [10^7, 256] activation.
 """
 import ctypes as C
+from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.library import custom_op, register_autograd
 
 from . import placement
 from ._lib import check, lib, ptr
 from .graph import _require_hip, _stream
 
+Tensor = torch.Tensor
 
-class _BatchNormAct(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu):
-        _require_hip(x, "x")
-        x = x if (x.dtype == torch.float32 and x.stride(-1) == 1) else x.float().contiguous()
-        L = lib()
-        N, d = x.shape
-        y = placement.empty_or_torch((N, d), x.device, reads=(x,))
-        mean = torch.empty(d, dtype=torch.float32, device=x.device)
-        invstd = torch.empty_like(mean)
-        var_u = torch.empty_like(mean)
-        w = None if weight is None else weight.detach().contiguous()
-        b = None if bias is None else bias.detach().contiguous()
-        with torch.cuda.device(x.device):
-            nb = C.c_size_t(0)
-            check(L.mp_bn_ws_bytes(N, d, C.byref(nb)))
-            ws = torch.empty(nb.value, dtype=torch.uint8, device=x.device)
-            check(L.mp_bn_train_fwd_f32(ptr(x), x.stride(0), N, d, ptr(w), ptr(b), float(eps), 1 if relu else 0,
-                                        ptr(y), y.stride(0), ptr(mean), ptr(invstd), ptr(var_u), ptr(ws), nb.value,
+
+def _bn_ws(N, d, device):
+    nb = C.c_size_t(0)
+    check(lib().mp_bn_ws_bytes(N, d, C.byref(nb)))
+    return torch.empty(nb.value, dtype=torch.uint8, device=device), nb.value
+
+
+@custom_op("mp::bn_fwd_raw", mutates_args=(), device_types="cuda")
+def _op_bn_fwd_raw(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps: float,
+                   relu: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """(y, mean, invstd, unbiased var) of BatchNorm1d over the node axis with batch statistics [+ ReLU]"""
+    _require_hip(x, "x")
+    x = x if (x.dtype == torch.float32 and x.stride(-1) == 1) else x.float().contiguous()
+    N, d = x.shape
+    y = placement.empty_or_torch((N, d), x.device, reads=(x,))
+    mean = torch.empty(d, dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    var_u = torch.empty_like(mean)
+    w = None if weight is None else weight.detach().contiguous()
+    b = None if bias is None else bias.detach().contiguous()
+    with torch.cuda.device(x.device):
+        ws, nb = _bn_ws(N, d, x.device)
+        check(lib().mp_bn_train_fwd_f32(ptr(x), x.stride(0), N, d, ptr(w), ptr(b), float(eps), 1 if relu else 0,
+                                        ptr(y), y.stride(0), ptr(mean), ptr(invstd), ptr(var_u), ptr(ws), nb,
                                         _stream()), "mp_bn_train_fwd_f32")
-        ctx.relu = relu
-        ctx.has_affine = (weight is not None, bias is not None)
-        ctx.save_for_backward(x, w, mean, invstd, y if relu else None)
-        ctx.mark_non_differentiable(mean, var_u)
-        return y, mean, var_u
+    return y, mean, invstd, var_u
 
-    @staticmethod
-    def backward(ctx, dy, _dmean, _dvar):
-        x, w, mean, invstd, y = ctx.saved_tensors
-        L = lib()
-        N, d = x.shape
-        dy = dy.contiguous()
-        dx = placement.empty_or_torch((N, d), x.device, reads=(dy, x))
-        dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty_like(dgamma)
-        with torch.cuda.device(x.device):
-            nb = C.c_size_t(0)
-            check(L.mp_bn_ws_bytes(N, d, C.byref(nb)))
-            ws = torch.empty(nb.value, dtype=torch.uint8, device=x.device)
-            check(L.mp_bn_train_bwd_f32(ptr(dy), dy.stride(0), ptr(y), y.stride(0) if y is not None else 0, ptr(x),
+
+@_op_bn_fwd_raw.register_fake
+def _(x, weight, bias, eps, relu):
+    d = x.size(1)
+    return (x.new_empty(x.shape, dtype=torch.float32), x.new_empty((d,), dtype=torch.float32),
+            x.new_empty((d,), dtype=torch.float32), x.new_empty((d,), dtype=torch.float32))
+
+
+@custom_op("mp::bn_bwd_raw", mutates_args=(), device_types="cuda")
+def _op_bn_bwd_raw(dy: Tensor, y: Optional[Tensor], x: Tensor, weight: Optional[Tensor], mean: Tensor,
+                   invstd: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """(dx, dgamma, dbeta); y given = the forward's ReLU output (its mask is applied to dy on the fly)"""
+    x = x if (x.dtype == torch.float32 and x.stride(-1) == 1) else x.float().contiguous()
+    N, d = x.shape
+    dy = dy.contiguous()
+    dx = placement.empty_or_torch((N, d), x.device, reads=(dy, x))
+    dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    w = None if weight is None else weight.detach().contiguous()
+    with torch.cuda.device(x.device):
+        ws, nb = _bn_ws(N, d, x.device)
+        check(lib().mp_bn_train_bwd_f32(ptr(dy), dy.stride(0), ptr(y), y.stride(0) if y is not None else 0, ptr(x),
                                         x.stride(0), N, d, ptr(w), ptr(mean), ptr(invstd), ptr(dx), dx.stride(0),
-                                        ptr(dgamma), ptr(dbeta), ptr(ws), nb.value, _stream()), "mp_bn_train_bwd_f32")
-        return dx, (dgamma if ctx.has_affine[0] else None), (dbeta if ctx.has_affine[1] else None), None, None
+                                        ptr(dgamma), ptr(dbeta), ptr(ws), nb, _stream()), "mp_bn_train_bwd_f32")
+    return dx, dgamma, dbeta
+
+
+@_op_bn_bwd_raw.register_fake
+def _(dy, y, x, weight, mean, invstd):
+    d = x.size(1)
+    return (x.new_empty(x.shape, dtype=torch.float32), x.new_empty((d,), dtype=torch.float32),
+            x.new_empty((d,), dtype=torch.float32))
+
+
+@custom_op("mp::bn_act", mutates_args=(), device_types="cuda")
+def _op_bn_act(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps: float,
+               relu: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """graphgym/models/layer.py:26-35 (BatchNorm1d, then the activation) in training mode: (y, mean, invstd, var)"""
+    return torch.ops.mp.bn_fwd_raw(x, weight, bias, eps, relu)
+
+
+@_op_bn_act.register_fake
+def _(x, weight, bias, eps, relu):
+    d = x.size(1)
+    return (x.new_empty(x.shape, dtype=torch.float32), x.new_empty((d,), dtype=torch.float32),
+            x.new_empty((d,), dtype=torch.float32), x.new_empty((d,), dtype=torch.float32))
+
+
+def _bn_setup(ctx, inputs, output):
+    x, weight, bias, eps, relu = inputs
+    y, mean, invstd, _ = output
+    ctx.relu = relu
+    ctx.has_affine = (weight is not None, bias is not None)
+    ctx.save_for_backward(x, weight, mean, invstd, y if relu else None)
+
+
+def _bn_backward(ctx, dy, _dmean, _dinvstd, _dvar):
+    x, w, mean, invstd, y = ctx.saved_tensors
+    dx, dgamma, dbeta = torch.ops.mp.bn_bwd_raw(dy, y, x, w, mean, invstd)
+    return dx, (dgamma if ctx.has_affine[0] else None), (dbeta if ctx.has_affine[1] else None), None, None
+
+
+register_autograd("mp::bn_act", _bn_backward, setup_context=_bn_setup)
 
 
 class BatchNorm1d(nn.BatchNorm1d):
@@ -78,7 +128,7 @@ class BatchNorm1d(nn.BatchNorm1d):
         if not (use_batch_stats and x.is_cuda and x.size(0) > 1):
             y = super().forward(x)
             return torch.relu(y) if self.relu else y
-        y, mean, var_u = _BatchNormAct.apply(x, self.weight, self.bias, self.eps, self.relu)
+        y, mean, _, var_u = torch.ops.mp.bn_act(x, self.weight, self.bias, float(self.eps), bool(self.relu))
         if self.training and self.track_running_stats:
             with torch.no_grad():
                 self.num_batches_tracked += 1

@@ -44,56 +44,7 @@ def _raw_spmm(g, x, reduce, S=None, self_scale=0.0, bias=None, relu=False, want_
     return y, argmax
 
 
-class _SpMM(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, bias, g, reduce, self_scale, relu):
-        x = _f32c(x, "x")
-        if x.size(0) != g.num_cols:
-            raise ValueError(f"x has {x.size(0)} rows, the operator has {g.num_cols} columns")
-        S = x if self_scale != 0.0 else None
-        b = None if bias is None else bias.detach().contiguous()
-        y, argmax = _raw_spmm(g, x, reduce, S=S, self_scale=self_scale, bias=b, relu=relu,
-                              want_argmax=(reduce == _lib.MAX))
-        ctx.g, ctx.reduce, ctx.self_scale, ctx.relu = g, reduce, self_scale, relu
-        ctx.has_bias = bias is not None
-        ctx.save_for_backward(y if relu else None, argmax)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        y, argmax = ctx.saved_tensors
-        g = ctx.g
-        dy = dy.contiguous()
-        if ctx.relu:
-            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)    # one vectorised pass
-        dbias = dy.sum(0) if ctx.has_bias else None
-        dx = None
-        if ctx.needs_input_grad[0]:
-            S = dy if ctx.self_scale != 0.0 else None
-            if ctx.reduce == _lib.SUM:
-                gt = g.transpose()
-                dx, _ = _raw_spmm(gt, dy, _lib.SUM, S=S, self_scale=ctx.self_scale)
-            elif ctx.reduce == _lib.MEAN:
-                gt = g.transpose_mean()
-                dx, _ = _raw_spmm(gt, dy, _lib.SUM, S=S, self_scale=ctx.self_scale)
-            else:
-                L = lib()
-                N, d = dy.shape
-                dx = torch.zeros((g.num_cols, d), dtype=torch.float32, device=dy.device)
-                with torch.cuda.device(dy.device):
-                    check(L.mp_spmm_max_bwd_f32(ptr(g.col), ptr(g.val), ptr(argmax), ptr(dy), dy.stride(0),
-                                                N, d, ptr(dx), dx.stride(0), _stream()), "mp_spmm_max_bwd_f32")
-                if ctx.self_scale != 0.0:
-                    dx = dx + ctx.self_scale * dy
-        return dx, dbias, None, None, None, None
-
-
-def spmm(g, x, reduce="sum", self_scale=0.0, bias=None, relu=False):
-    """y[i] = act( reduce_{j in N(i)} w_ij x[j] + self_scale * x[i] + bias )
-
-    reduce: 'sum'/'add' | 'mean' | 'max'.  The gradient flows to x and bias; entry values
-    of g are constants here (attention weights go through spmm_edge_values)."""
-    return _SpMM.apply(x, bias, g, _lib.REDUCE[reduce], float(self_scale), bool(relu))
+# (spmm: registered operator mp::spmm, below)
 
 
 def spmm_fused_eval(g, x, reduce="sum", self_scale=0.0, col_scale=None, col_shift=None, relu=False,
@@ -128,47 +79,6 @@ def spmm_fused_eval(g, x, reduce="sum", self_scale=0.0, col_scale=None, col_shif
             return torch.nn.functional.normalize(y, p=2, dim=-1, eps=l2_eps)
         check(st, "mp_spmm_csr_epilogue_f32")
     return y
-
-
-class _IdAgg(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, g, id_index, col_marked):
-        x = _f32c(x, "x")
-        L = lib()
-        N, d = g.num_nodes, x.size(1)
-        P = placement.empty_or_torch((N, d), x.device, reads=(x,))
-        Q = placement.empty_or_torch((N, d), x.device, reads=(x,))
-        plan, counts = g.plan()
-        with torch.cuda.device(x.device):
-            nb = C.c_size_t(0)
-            check(L.mp_spmm_ws_bytes(counts, d, _lib.SUM, 1, C.byref(nb)))
-            ws = torch.empty(nb.value, dtype=torch.uint8, device=x.device) if nb.value else None
-            check(L.mp_idgnn_agg_f32(ptr(g.rowptr), ptr(col_marked), ptr(g.val), N, ptr(plan), counts,
-                                     ptr(x), x.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0), d,
-                                     ptr(ws), nb.value, _stream()), "mp_idgnn_agg_f32")
-        ctx.g = g
-        ctx.save_for_backward(id_index)
-        return P, Q
-
-    @staticmethod
-    def backward(ctx, dP, dQ):
-        (id_index,) = ctx.saved_tensors
-        gt = ctx.g.transpose()
-        dx, _ = _raw_spmm(gt, dP.contiguous(), _lib.SUM)
-        # Q = A S x  =>  dx[id] += (A^T dQ)[id]: only the identity nodes' rows of A^T are needed, an
-        # aggregation over their out-edges alone (a [n_id, N] operator), not a second full pass
-        sub = gt.select_rows(id_index)
-        t, _ = _raw_spmm(sub, dQ.contiguous(), _lib.SUM)
-        dx.index_add_(0, id_index, t)
-        return dx, None, None, None
-
-
-def idgnn_aggregate(g, id_index, x, col_marked=None):
-    """(P, Q) with P = A x and Q = A S x, S selecting the identity nodes' rows: one pass over
-    the edges.  P @ W + Q @ W_id equals A (x W + S x W_id) of gcn_id (TfgIDLayer.py:510-517)."""
-    if col_marked is None:
-        col_marked = g.mark_ids(id_index)
-    return _IdAgg.apply(x, g, id_index.to(torch.int64), col_marked)
 
 
 def _raw_dense_fused(P, W, Q, W_id, bias, relu):
@@ -257,158 +167,6 @@ def _wgrad_and_bias(X, g, need_w, need_b):
         if dW is None:
             dW = X.t() @ g
     return dW, (g.sum(0) if need_b else None)
-
-
-class _DenseFused(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, P, W, Q, W_id, bias, relu):
-        Pc = _f32c(P, "P")
-        Qc = None if Q is None else _f32c(Q, "Q")
-        if Qc is None and bias is None and not relu:
-            # a plain product has nothing to fuse: the library GEMM (scripts/gemm_layouts.py: 9.9 vs 11.8 ms at
-            # 10^7 x 256 x 256); the engine's kernel earns its keep when bias / activation / a second product ride along
-            out = torch.mm(Pc, W.detach())
-        else:
-            out = _raw_dense_fused(Pc, W.detach(), Qc, None if W_id is None else W_id.detach(),
-                                   None if bias is None else bias.detach(), relu)
-        if out is None:     # shape outside the fused kernel: library GEMMs
-            out = Pc @ W.detach()
-            if Qc is not None:
-                out = out + Qc @ W_id.detach()
-            if bias is not None:
-                out = out + bias.detach()
-            if relu:
-                out = torch.relu(out)
-        ctx.relu = relu
-        ctx.save_for_backward(Pc, W, Qc, W_id, out if relu else None)
-        ctx.has_bias = bias is not None
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        P, W, Q, W_id, out = ctx.saved_tensors
-        if ctx.relu:
-            g = torch.ops.aten.threshold_backward(g, out, 0.0)
-        g = g.contiguous()
-
-        def times_wt(Wm):   # g @ Wm^T: a plain product -> library GEMM (9.8 vs 11.8 ms at 10^7 x 256 x 256)
-            return torch.mm(g, Wm.detach().t())
-        def wgrad(Xm):      # Xm^T @ g
-            r = _raw_dense_wgrad(Xm, g)
-            return r if r is not None else Xm.t() @ g
-        dP = times_wt(W) if ctx.needs_input_grad[0] else None
-        dW, db = _wgrad_and_bias(P, g, ctx.needs_input_grad[1], ctx.has_bias)
-        dQ = times_wt(W_id) if (Q is not None and ctx.needs_input_grad[2]) else None
-        dWid = wgrad(Q) if (Q is not None and ctx.needs_input_grad[3]) else None
-        return dP, dW, dQ, dWid, db, None
-
-
-class _AggDense(torch.autograd.Function):
-    """out = act((A x + self_scale * x) W + bias) as one kernel; the backward pass runs the same kernel on the
-    transposed operator: dx = (A' g + self_scale * g) W', dW = P' g with P kept by the forward launch."""
-    @staticmethod
-    def forward(ctx, x, W, bias, g, self_scale, relu, grad_mode):
-        x = _f32c(x, "x")
-        if x.size(0) != g.num_cols:
-            raise ValueError(f"x has {x.size(0)} rows, the operator has {g.num_cols} columns")
-        if g.num_cols != g.num_nodes and self_scale != 0.0:
-            raise ValueError("the self term needs a square operator")
-        need_w = ctx.needs_input_grad[1] and grad_mode   # inference (no_grad): no P rows written
-        out, P = _raw_agg_dense(g, x, W.detach(), None if bias is None else bias.detach(), relu,
-                                S=x if self_scale != 0.0 else None, self_scale=self_scale, want_P=need_w)
-        ctx.g, ctx.self_scale, ctx.relu, ctx.has_bias = g, self_scale, relu, bias is not None
-        ctx.save_for_backward(P, W, out if relu else None)
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        P, W, out = ctx.saved_tensors
-        gm = gout.contiguous()
-        if ctx.relu:
-            gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
-        dW, db = _wgrad_and_bias(P, gm, ctx.needs_input_grad[1], ctx.has_bias)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            gt = ctx.g.transpose()
-            Wt = W.detach().t().contiguous()
-            S = gm if ctx.self_scale != 0.0 else None
-            if agg_dense_supported(gt, gm, Wt):
-                dx, _ = _raw_agg_dense(gt, gm, Wt, None, False, S=S, self_scale=ctx.self_scale)
-            else:
-                T, _ = _raw_spmm(gt, gm, _lib.SUM, S=S, self_scale=ctx.self_scale)
-                dx = torch.mm(T, Wt)
-        return dx, dW, db, None, None, None, None
-
-
-class _AggDenseID(torch.autograd.Function):
-    """out = act(A (x W + S x W_id) + b) = act((A x) W + b + A_id Z), Z = x[id] W_id  (gcn_id, TfgIDLayer.py:510-523;
-    GCNIDConvLayer.forward, idconv.py:150-177): the one-kernel aggregate -> transform plus the identity branch as a
-    small product and a fix-up of the few rows next to an identity node (mp_id_fixup_f32).  Backward: the same
-    kernel on the transposed operator for dx, and the identity branch through A_id^T g (an [n_id, N] aggregation)."""
-    @staticmethod
-    def forward(ctx, x, W, W_id, bias, g, ids, self_scale, relu, grad_mode):
-        x = _f32c(x, "x")
-        if x.size(0) != g.num_cols or g.num_cols != g.num_nodes:
-            raise ValueError("the identity branch needs a square operator over the rows of x")
-        br = g.id_branch(ids)
-        ids = ids.to(torch.int64)
-        x_id = x.index_select(0, ids)
-        Z = torch.mm(x_id, W_id.detach())
-        need_w = ctx.needs_input_grad[1] and grad_mode
-        out, P = _raw_agg_dense(g, x, W.detach(), None if bias is None else bias.detach(), relu,
-                                S=x if self_scale != 0.0 else None, self_scale=self_scale, want_P=need_w,
-                                defer_act=br.defer)
-        with torch.cuda.device(x.device):
-            check(lib().mp_id_fixup_f32(ptr(br.rows), ptr(br.crp), ptr(br.slot), ptr(br.val), br.n_rows, ptr(Z),
-                                        Z.stride(0), ptr(out), out.stride(0), out.size(1),
-                                        _lib.ACT_RELU if relu else _lib.ACT_NONE, _stream()), "mp_id_fixup_f32")
-        ctx.g, ctx.br, ctx.self_scale, ctx.relu, ctx.has_bias = g, br, self_scale, relu, bias is not None
-        ctx.save_for_backward(P, W, W_id, x_id, ids, out if relu else None)
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        P, W, W_id, x_id, ids, out = ctx.saved_tensors
-        gm = gout.contiguous()
-        if ctx.relu:
-            gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
-        dW, db = _wgrad_and_bias(P, gm, ctx.needs_input_grad[1], ctx.has_bias)
-        # identity branch: T = A_id^T g  [n_id, d_out];  dW_id = x_id^T T ;  dx[id] += T W_id^T
-        T = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
-            T, _ = _raw_spmm(ctx.br.t, gm, _lib.SUM)
-        dWid = torch.mm(x_id.t(), T) if ctx.needs_input_grad[2] else None
-        dx = None
-        if ctx.needs_input_grad[0]:
-            gt = ctx.g.transpose()
-            Wt = W.detach().t().contiguous()
-            S = gm if ctx.self_scale != 0.0 else None
-            if agg_dense_supported(gt, gm, Wt):
-                dx, _ = _raw_agg_dense(gt, gm, Wt, None, False, S=S, self_scale=ctx.self_scale)
-            else:
-                A, _ = _raw_spmm(gt, gm, _lib.SUM, S=S, self_scale=ctx.self_scale)
-                dx = torch.mm(A, Wt)
-            dx.index_add_(0, ids, torch.mm(T, W_id.detach().t()))
-        return dx, dW, dWid, db, None, None, None, None, None
-
-
-def agg_dense_id(g, x, W, W_id, id_index, bias=None, relu=False, self_scale=0.0):
-    """act(A (x W + S x W_id) + bias) with S selecting the identity nodes' rows: one aggregate -> transform launch plus
-    the identity branch's small product and row fix-up; None when the shapes are outside the one-kernel layer (the
-    caller then runs idgnn_aggregate + dense_fused)"""
-    if not (agg_dense_supported(g, x, W) and x.dtype == torch.float32 and g.num_cols == g.num_nodes):
-        return None
-    return _AggDenseID.apply(x, W, W_id, bias, g, id_index, float(self_scale), bool(relu), torch.is_grad_enabled())
-
-
-def agg_dense(g, x, W, bias=None, relu=False, self_scale=0.0):
-    """act((sum_{j in N(i)} w_ij x[j] + self_scale * x[i]) W + bias): aggregation and the feature transform
-    that follows it in ONE kernel (mp_agg_dense_f32) when the shapes allow (agg_dense_supported), otherwise
-    the aggregation kernel followed by the fused transform"""
-    if agg_dense_supported(g, x, W) and x.dtype == torch.float32:
-        # grad mode is read here: inside Function.forward it is always off
-        return _AggDense.apply(x, W, bias, g, float(self_scale), bool(relu), torch.is_grad_enabled())
-    return dense_fused(spmm(g, x, "sum", self_scale=self_scale), W, bias=bias, relu=relu)
 
 
 def _dense_into(out_view, P, W, bias, relu):
@@ -514,11 +272,6 @@ def sage_concat(g, x, Ws, Wn, bias=None, relu=False):
             and g.num_cols == g.num_nodes):
         return _SageConcatFused.apply(x, Ws, Wn, bias, g, bool(relu), torch.is_grad_enabled())
     return concat_dense(x, spmm(g, x, "mean"), Ws, Wn, bias, relu=relu)
-
-
-def dense_fused(P, W, Q=None, W_id=None, bias=None, relu=False):
-    """act(P @ W [+ Q @ W_id] + bias) in one kernel (mp_dense_fused_f32); gradients through library GEMMs"""
-    return _DenseFused.apply(P, W, Q, W_id, bias, bool(relu))
 
 
 class _IndexAddRows(torch.autograd.Function):
@@ -725,3 +478,481 @@ class _SpmmEdgeValues(torch.autograd.Function):
 
 def spmm_edge_values(g, a, V, heads=1):
     return _SpmmEdgeValues.apply(a, V, g, int(heads))
+
+
+# =========================================================================================
+# Registered operators: torch.ops.mp.*
+#
+# The path's operators as PyTorch custom ops (torch.library): schemas, fake (meta) kernels for tracing /
+# torch.compile / opcheck, autograd formulas built from other registered ops.  A graph crosses the boundary as
+# an int handle (CSRGraph.handle): custom ops take tensors and scalars only, and the CSR, its plan and its cached
+# transpose belong to the batch, not to a call.  `*_raw` ops are single launches of a C-ABI entry point (no
+# autograd); the un-suffixed ops are what the layers call.
+#
+#   mp::spmm            y = act(reduce_j w_ij x_j + s x_i + b)         SparseAdj.matmul, sparse_adj.py:91-97
+#   mp::idgnn_agg       (P, Q) = (A x, A S x)                          gcn_id two-branch form, TfgIDLayer.py:510-517
+#   mp::agg_dense       act((A x + s x) W + b), one launch             aggregate -> kernel product, TfgIDLayer.py:510-523
+#   mp::agg_dense_id    act(A (x W + S x W_id) + b)                    gcn_id / GCNIDConvLayer, idconv.py:150-177
+#   mp::dense_fused     act(P W [+ Q W_id] + b)                        the transform after the aggregation
+#   mp::bn_act          BatchNorm1d (training statistics) [+ ReLU]     graphgym/models/layer.py:26-35
+# =========================================================================================
+from typing import Optional, Tuple   # noqa: E402
+
+from torch.library import custom_op, register_autograd   # noqa: E402
+
+from .graph import from_handle   # noqa: E402
+
+Tensor = torch.Tensor
+
+
+def _none_if_empty(t):
+    return None if t is None or t.numel() == 0 else t
+
+
+def _empty_like_none(ref, dtype=torch.float32):
+    return torch.empty((0,), dtype=dtype, device=ref.device)
+
+
+# ---- raw launches -------------------------------------------------------------------------
+@custom_op("mp::spmm_raw", mutates_args=(), device_types="cuda")
+def _op_spmm_raw(x: Tensor, graph: int, variant: int, reduce: int, S: Optional[Tensor], self_scale: float,
+                 bias: Optional[Tensor], relu: bool, want_argmax: bool) -> Tuple[Tensor, Tensor]:
+    g = from_handle(graph).variant(variant)
+    x = _f32c(x, "x")
+    if x.size(0) != g.num_cols:
+        raise ValueError(f"x has {x.size(0)} rows, the operator has {g.num_cols} columns")
+    Sc = None if S is None else _f32c(S, "S")
+    y, argmax = _raw_spmm(g, x, reduce, S=Sc, self_scale=self_scale, bias=None if bias is None else bias.contiguous(),
+                          relu=relu, want_argmax=want_argmax)
+    return y, (argmax if argmax is not None else _empty_like_none(x, torch.int32))
+
+
+@_op_spmm_raw.register_fake
+def _(x, graph, variant, reduce, S, self_scale, bias, relu, want_argmax):
+    g = from_handle(graph)
+    n = g.num_nodes if variant == 0 else g.num_cols
+    return (x.new_empty((n, x.size(1)), dtype=torch.float32),
+            x.new_empty((n, x.size(1)) if want_argmax else (0,), dtype=torch.int32))
+
+
+@custom_op("mp::spmm_rows_raw", mutates_args=(), device_types="cuda")
+def _op_spmm_rows_raw(x: Tensor, graph: int, variant: int, rows: Tensor) -> Tensor:
+    """sum aggregation over the listed rows only of a graph variant: an [len(rows), n] operator"""
+    sub = from_handle(graph).variant(variant).select_rows(rows)
+    y, _ = _raw_spmm(sub, _f32c(x, "x"), _lib.SUM)
+    return y
+
+
+@_op_spmm_rows_raw.register_fake
+def _(x, graph, variant, rows):
+    return x.new_empty((rows.numel(), x.size(1)), dtype=torch.float32)
+
+
+@custom_op("mp::spmm_max_bwd_raw", mutates_args=(), device_types="cuda")
+def _op_spmm_max_bwd_raw(dy: Tensor, argmax: Tensor, graph: int) -> Tensor:
+    g = from_handle(graph)
+    dy = dy.contiguous()
+    N, d = dy.shape
+    dx = torch.zeros((g.num_cols, d), dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        check(lib().mp_spmm_max_bwd_f32(ptr(g.col), ptr(g.val), ptr(argmax), ptr(dy), dy.stride(0), N, d, ptr(dx),
+                                        dx.stride(0), _stream()), "mp_spmm_max_bwd_f32")
+    return dx
+
+
+@_op_spmm_max_bwd_raw.register_fake
+def _(dy, argmax, graph):
+    return dy.new_empty((from_handle(graph).num_cols, dy.size(1)))
+
+
+@custom_op("mp::idgnn_agg_raw", mutates_args=(), device_types="cuda")
+def _op_idgnn_agg_raw(x: Tensor, graph: int, id_index: Tensor) -> Tuple[Tensor, Tensor]:
+    g = from_handle(graph)
+    x = _f32c(x, "x")
+    col_marked = g.mark_ids(id_index)
+    L = lib()
+    N, d = g.num_nodes, x.size(1)
+    P = placement.empty_or_torch((N, d), x.device, reads=(x,))
+    Q = placement.empty_or_torch((N, d), x.device, reads=(x,))
+    plan, counts = g.plan()
+    with torch.cuda.device(x.device):
+        nb = C.c_size_t(0)
+        check(L.mp_spmm_ws_bytes(counts, d, _lib.SUM, 1, C.byref(nb)))
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=x.device) if nb.value else None
+        check(L.mp_idgnn_agg_f32(ptr(g.rowptr), ptr(col_marked), ptr(g.val), N, ptr(plan), counts,
+                                 ptr(x), x.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0), d,
+                                 ptr(ws), nb.value, _stream()), "mp_idgnn_agg_f32")
+    return P, Q
+
+
+@_op_idgnn_agg_raw.register_fake
+def _(x, graph, id_index):
+    n = from_handle(graph).num_nodes
+    return x.new_empty((n, x.size(1))), x.new_empty((n, x.size(1)))
+
+
+def _agg_dense_kernel_ok(g, x, W, S=None):
+    """the one-kernel aggregate -> transform covers these operands (shapes, alignment, row lengths)"""
+    return (agg_dense_supported(g, x, W) and x.dtype == torch.float32
+            and (S is None or (S.stride(0) % 4 == 0 and S.data_ptr() % 16 == 0)))
+
+
+@custom_op("mp::agg_dense_raw", mutates_args=(), device_types="cuda")
+def _op_agg_dense_raw(x: Tensor, W: Tensor, bias: Optional[Tensor], graph: int, variant: int, reduce: int,
+                      S: Optional[Tensor], self_scale: float, relu: bool, want_P: bool) -> Tuple[Tensor, Tensor]:
+    """act((reduce_j w_ij x_j + s S_i) W + b): ONE launch where mp_agg_dense_f32 covers the operands, otherwise the
+    aggregation kernel followed by the fused transform; returns (out, aggregated rows or an empty tensor)"""
+    g = from_handle(graph).variant(variant)
+    x = _f32c(x, "x")
+    Sc = None if S is None else _f32c(S, "S")
+    Wd = W.detach()
+    if _agg_dense_kernel_ok(g, x, Wd, Sc):
+        out, P = _raw_agg_dense(g, x, Wd, None if bias is None else bias.detach(), relu, S=Sc,
+                                self_scale=self_scale, want_P=want_P, reduce=reduce)
+    else:
+        P, _ = _raw_spmm(g, x, reduce, S=Sc, self_scale=self_scale)
+        out = _dense_any(P, Wd, None, None, bias, relu)
+    return out, (P if (want_P and P is not None) else _empty_like_none(x))
+
+
+@_op_agg_dense_raw.register_fake
+def _(x, W, bias, graph, variant, reduce, S, self_scale, relu, want_P):
+    g = from_handle(graph)
+    n = g.num_nodes if variant == 0 else g.num_cols
+    return x.new_empty((n, W.size(1))), x.new_empty((n, x.size(1)) if want_P else (0,))
+
+
+@custom_op("mp::agg_dense_id_raw", mutates_args=(), device_types="cuda")
+def _op_agg_dense_id_raw(x: Tensor, W: Tensor, W_id: Tensor, bias: Optional[Tensor], graph: int, id_index: Tensor,
+                         self_scale: float, relu: bool, want_P: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """act((A x + s x) W + b + A_id Z), Z = x[id] W_id: the one-kernel layer with the activation deferred on the rows
+    next to an identity node, then mp_id_fixup_f32 on those rows; returns (out, aggregated rows or empty, x[id])"""
+    g = from_handle(graph)
+    x = _f32c(x, "x")
+    br = g.id_branch(id_index)
+    ids = id_index.to(torch.int64)
+    x_id = x.index_select(0, ids)
+    Z = torch.mm(x_id, W_id.detach())
+    Wd = W.detach()
+    S = x if self_scale != 0.0 else None
+    b = None if bias is None else bias.detach()
+    if _agg_dense_kernel_ok(g, x, Wd, S):
+        out, P = _raw_agg_dense(g, x, Wd, b, relu, S=S, self_scale=self_scale, want_P=want_P, defer_act=br.defer)
+        act = _lib.ACT_RELU if relu else _lib.ACT_NONE
+    else:   # shapes outside the one-kernel layer: aggregation kernel, transform without activation, then the fix-up
+        P, _ = _raw_spmm(g, x, _lib.SUM, S=S, self_scale=self_scale)
+        out = _dense_any(P, Wd, None, None, b, False)
+        act = _lib.ACT_NONE
+    with torch.cuda.device(x.device):
+        check(lib().mp_id_fixup_f32(ptr(br.rows), ptr(br.crp), ptr(br.slot), ptr(br.val), br.n_rows, ptr(Z),
+                                    Z.stride(0), ptr(out), out.stride(0), out.size(1), act, _stream()),
+              "mp_id_fixup_f32")
+    if relu and act == _lib.ACT_NONE:
+        out = torch.relu_(out)
+    return out, (P if (want_P and P is not None) else _empty_like_none(x)), x_id
+
+
+@_op_agg_dense_id_raw.register_fake
+def _(x, W, W_id, bias, graph, id_index, self_scale, relu, want_P):
+    n = from_handle(graph).num_nodes
+    return (x.new_empty((n, W.size(1))), x.new_empty((n, x.size(1)) if want_P else (0,)),
+            x.new_empty((id_index.numel(), x.size(1))))
+
+
+@custom_op("mp::id_branch_t_raw", mutates_args=(), device_types="cuda")
+def _op_id_branch_t_raw(gm: Tensor, graph: int, id_index: Tensor) -> Tensor:
+    """T = A_id^T g  [n_id, d]: the gradient reaching Z = x[id] W_id"""
+    br = from_handle(graph).id_branch(id_index)
+    T, _ = _raw_spmm(br.t, _f32c(gm, "g"), _lib.SUM)
+    return T
+
+
+@_op_id_branch_t_raw.register_fake
+def _(gm, graph, id_index):
+    return gm.new_empty((id_index.numel(), gm.size(1)))
+
+
+def _dense_any(P, W, Q, W_id, bias, relu):
+    """act(P W [+ Q W_id] + b): the engine's MFMA kernel where it pays / applies, library GEMMs otherwise"""
+    Pc = _f32c(P, "P")
+    Qc = None if Q is None else _f32c(Q, "Q")
+    out = None
+    if Qc is None and bias is None and not relu:
+        # a plain product has nothing to fuse: the library GEMM (scripts/gemm_layouts.py: 9.9 vs 11.8 ms at
+        # 10^7 x 256 x 256); the engine's kernel earns its keep when bias / activation / a second product ride along
+        return torch.mm(Pc, W)
+    out = _raw_dense_fused(Pc, W, Qc, W_id, bias, relu)
+    if out is None:     # shape outside the fused kernel: library GEMMs
+        out = Pc @ W
+        if Qc is not None:
+            out = out + Qc @ W_id
+        if bias is not None:
+            out = out + bias
+        if relu:
+            out = torch.relu(out)
+    return out
+
+
+@custom_op("mp::dense_fused_raw", mutates_args=(), device_types="cuda")
+def _op_dense_fused_raw(P: Tensor, W: Tensor, Q: Optional[Tensor], W_id: Optional[Tensor], bias: Optional[Tensor],
+                        relu: bool) -> Tensor:
+    return _dense_any(P, W.detach(), Q, None if W_id is None else W_id.detach(),
+                      None if bias is None else bias.detach(), relu)
+
+
+@_op_dense_fused_raw.register_fake
+def _(P, W, Q, W_id, bias, relu):
+    return P.new_empty((P.size(0), W.size(1)))
+
+
+@custom_op("mp::dense_wgrad_raw", mutates_args=(), device_types="cuda")
+def _op_dense_wgrad_raw(X: Tensor, G: Tensor, want_w: bool, want_b: bool) -> Tuple[Tensor, Tensor]:
+    """(X^T G, column sums of G) in one pass over G (either may be skipped: an empty tensor comes back)"""
+    dW, db = _wgrad_and_bias(X, G.contiguous() if G.stride(-1) != 1 else G, want_w, want_b)
+    return (dW if dW is not None else _empty_like_none(G)), (db if db is not None else _empty_like_none(G))
+
+
+@_op_dense_wgrad_raw.register_fake
+def _(X, G, want_w, want_b):
+    return (G.new_empty((X.size(1), G.size(1)) if want_w else (0,)), G.new_empty((G.size(1),) if want_b else (0,)))
+
+
+# ---- differentiable operators ---------------------------------------------------------------
+@custom_op("mp::spmm", mutates_args=(), device_types="cuda")
+def _op_spmm(x: Tensor, graph: int, reduce: int, self_scale: float, bias: Optional[Tensor],
+             relu: bool) -> Tuple[Tensor, Tensor]:
+    return torch.ops.mp.spmm_raw(x, graph, 0, reduce, x if self_scale != 0.0 else None, self_scale, bias, relu,
+                                 reduce == _lib.MAX)
+
+
+@_op_spmm.register_fake
+def _(x, graph, reduce, self_scale, bias, relu):
+    n = from_handle(graph).num_nodes
+    return x.new_empty((n, x.size(1))), x.new_empty((n, x.size(1)) if reduce == _lib.MAX else (0,), dtype=torch.int32)
+
+
+def _spmm_setup(ctx, inputs, output):
+    x, graph, reduce, self_scale, bias, relu = inputs
+    y, argmax = output
+    ctx.graph, ctx.reduce, ctx.self_scale, ctx.relu = graph, reduce, self_scale, relu
+    ctx.g_alive = from_handle(graph)
+    ctx.has_bias = bias is not None
+    ctx.save_for_backward(y if relu else None, argmax)
+
+
+def _spmm_backward(ctx, dy, _dargmax):
+    y, argmax = ctx.saved_tensors
+    dy = dy.contiguous()
+    if ctx.relu:
+        dy = torch.ops.aten.threshold_backward(dy, y, 0.0)    # one vectorised pass
+    dbias = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
+    dx = None
+    if ctx.needs_input_grad[0]:
+        S = dy if ctx.self_scale != 0.0 else None
+        if ctx.reduce == _lib.MAX:
+            dx = torch.ops.mp.spmm_max_bwd_raw(dy, argmax, ctx.graph)
+            if ctx.self_scale != 0.0:
+                dx = dx + ctx.self_scale * dy
+        else:   # the same kernel on the transposed operator (mean: entries w / count(row))
+            dx = torch.ops.mp.spmm_raw(dy, ctx.graph, 1 if ctx.reduce == _lib.SUM else 2, _lib.SUM, S,
+                                       ctx.self_scale, None, False, False)[0]
+    return dx, None, None, None, dbias, None
+
+
+register_autograd("mp::spmm", _spmm_backward, setup_context=_spmm_setup)
+
+
+def spmm(g, x, reduce="sum", self_scale=0.0, bias=None, relu=False):
+    """y[i] = act( reduce_{j in N(i)} w_ij x[j] + self_scale * x[i] + bias )   (torch.ops.mp.spmm)
+
+    reduce: 'sum'/'add' | 'mean' | 'max'.  The gradient flows to x and bias; entry values
+    of g are constants here (attention weights go through spmm_edge_values)."""
+    _require_hip(x, "x")
+    return torch.ops.mp.spmm(x, g.handle, _lib.REDUCE[reduce], float(self_scale), bias, bool(relu))[0]
+
+
+@custom_op("mp::idgnn_agg", mutates_args=(), device_types="cuda")
+def _op_idgnn_agg(x: Tensor, graph: int, id_index: Tensor) -> Tuple[Tensor, Tensor]:
+    return torch.ops.mp.idgnn_agg_raw(x, graph, id_index)
+
+
+@_op_idgnn_agg.register_fake
+def _(x, graph, id_index):
+    n = from_handle(graph).num_nodes
+    return x.new_empty((n, x.size(1))), x.new_empty((n, x.size(1)))
+
+
+def _idgnn_setup(ctx, inputs, output):
+    x, graph, id_index = inputs
+    ctx.graph, ctx.g_alive = graph, from_handle(graph)
+    ctx.save_for_backward(id_index)
+
+
+def _idgnn_backward(ctx, dP, dQ):
+    (id_index,) = ctx.saved_tensors
+    dx = torch.ops.mp.spmm_raw(dP.contiguous(), ctx.graph, 1, _lib.SUM, None, 0.0, None, False, False)[0]
+    # Q = A S x  =>  dx[id] += (A^T dQ)[id]: only the identity nodes' rows of A^T are needed, an
+    # aggregation over their out-edges alone (an [n_id, N] operator), not a second full pass
+    t = torch.ops.mp.spmm_rows_raw(dQ.contiguous(), ctx.graph, 1, id_index)
+    return dx.index_add(0, id_index.to(torch.int64), t), None, None
+
+
+register_autograd("mp::idgnn_agg", _idgnn_backward, setup_context=_idgnn_setup)
+
+
+def idgnn_aggregate(g, id_index, x, col_marked=None):
+    """(P, Q) with P = A x and Q = A S x, S selecting the identity nodes' rows: one pass over
+    the edges.  P @ W + Q @ W_id equals A (x W + S x W_id) of gcn_id (TfgIDLayer.py:510-517)."""
+    _require_hip(x, "x")
+    return torch.ops.mp.idgnn_agg(x, g.handle, id_index)
+
+
+@custom_op("mp::dense_fused", mutates_args=(), device_types="cuda")
+def _op_dense_fused(P: Tensor, W: Tensor, Q: Optional[Tensor], W_id: Optional[Tensor], bias: Optional[Tensor],
+                    relu: bool) -> Tensor:
+    return torch.ops.mp.dense_fused_raw(P, W, Q, W_id, bias, relu)
+
+
+@_op_dense_fused.register_fake
+def _(P, W, Q, W_id, bias, relu):
+    return P.new_empty((P.size(0), W.size(1)))
+
+
+def _dense_setup(ctx, inputs, output):
+    P, W, Q, W_id, bias, relu = inputs
+    ctx.relu, ctx.has_q, ctx.has_bias = relu, Q is not None, bias is not None
+    ctx.save_for_backward(P, W, Q, W_id, output if relu else None)
+
+
+def _dense_backward(ctx, g):
+    P, W, Q, W_id, out = ctx.saved_tensors
+    if ctx.relu:
+        g = torch.ops.aten.threshold_backward(g, out, 0.0)
+    g = g.contiguous()
+    need = ctx.needs_input_grad
+    # g @ W^T is a plain product -> library GEMM (9.8 vs 11.8 ms at 10^7 x 256 x 256); the weight and bias gradients
+    # come out of one pass of the engine's split-K kernel
+    dP = torch.mm(g, W.t()) if need[0] else None
+    dW, db = torch.ops.mp.dense_wgrad_raw(P, g, need[1], ctx.has_bias and need[4])
+    dQ = torch.mm(g, W_id.t()) if (ctx.has_q and need[2]) else None
+    dWid = torch.ops.mp.dense_wgrad_raw(Q, g, True, False)[0] if (ctx.has_q and need[3]) else None
+    return dP, _none_if_empty(dW), dQ, dWid, _none_if_empty(db), None
+
+
+register_autograd("mp::dense_fused", _dense_backward, setup_context=_dense_setup)
+
+
+def dense_fused(P, W, Q=None, W_id=None, bias=None, relu=False):
+    """act(P @ W [+ Q @ W_id] + bias) in one kernel (torch.ops.mp.dense_fused; mp_dense_fused_f32)"""
+    _require_hip(P, "P")
+    return torch.ops.mp.dense_fused(P, W, Q, W_id, bias, bool(relu))
+
+
+@custom_op("mp::agg_dense", mutates_args=(), device_types="cuda")
+def _op_agg_dense(x: Tensor, W: Tensor, bias: Optional[Tensor], graph: int, reduce: int, self_scale: float,
+                  relu: bool, want_P: bool) -> Tuple[Tensor, Tensor]:
+    return torch.ops.mp.agg_dense_raw(x, W, bias, graph, 0, reduce, x if self_scale != 0.0 else None, self_scale, relu,
+                                      want_P)
+
+
+@_op_agg_dense.register_fake
+def _(x, W, bias, graph, reduce, self_scale, relu, want_P):
+    n = from_handle(graph).num_nodes
+    return x.new_empty((n, W.size(1))), x.new_empty((n, x.size(1)) if want_P else (0,))
+
+
+def _agg_dense_setup(ctx, inputs, output):
+    x, W, bias, graph, reduce, self_scale, relu, want_P = inputs
+    out, P = output
+    ctx.graph, ctx.g_alive = graph, from_handle(graph)
+    ctx.reduce, ctx.self_scale, ctx.relu, ctx.has_bias, ctx.want_P = reduce, self_scale, relu, bias is not None, want_P
+    ctx.save_for_backward(P, W, out if relu else None, None if want_P else x)
+
+
+def _agg_dense_backward(ctx, gout, _gP):
+    P, W, out, x = ctx.saved_tensors
+    gm = gout.contiguous()
+    if ctx.relu:
+        gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
+    need = ctx.needs_input_grad
+    if not ctx.want_P and (need[1]):   # the aggregated rows were not kept (called outside grad mode bookkeeping)
+        P = torch.ops.mp.spmm_raw(x, ctx.graph, 0, ctx.reduce, x if ctx.self_scale != 0.0 else None, ctx.self_scale,
+                                  None, False, False)[0]
+    dW, db = torch.ops.mp.dense_wgrad_raw(P, gm, need[1], ctx.has_bias and need[2]) if (need[1] or need[2]) else (None, None)
+    dx = None
+    if need[0]:
+        # dx = (A^T g + s g) W^T: the same one-kernel layer on the transposed operator (mean: entries w / count)
+        variant = 1 if ctx.reduce == _lib.SUM else 2
+        dx = torch.ops.mp.agg_dense_raw(gm, W.t().contiguous(), None, ctx.graph, variant, _lib.SUM,
+                                        gm if ctx.self_scale != 0.0 else None, ctx.self_scale, False, False)[0]
+    return dx, _none_if_empty(dW), _none_if_empty(db), None, None, None, None, None
+
+
+register_autograd("mp::agg_dense", _agg_dense_backward, setup_context=_agg_dense_setup)
+
+
+def agg_dense(g, x, W, bias=None, relu=False, self_scale=0.0, reduce="sum"):
+    """act((reduce_{j in N(i)} w_ij x[j] + self_scale * x[i]) W + bias)  (torch.ops.mp.agg_dense): aggregation and
+    the feature transform that follows it in ONE kernel (mp_agg_dense_f32) when the shapes allow
+    (agg_dense_supported), otherwise the aggregation kernel followed by the fused transform"""
+    _require_hip(x, "x")
+    if g.num_cols != g.num_nodes and self_scale != 0.0:
+        raise ValueError("the self term needs a square operator")
+    want_P = torch.is_grad_enabled() and W.requires_grad     # inference: no aggregated rows written
+    return torch.ops.mp.agg_dense(x, W, bias, g.handle, _lib.REDUCE[reduce], float(self_scale), bool(relu), want_P)[0]
+
+
+@custom_op("mp::agg_dense_id", mutates_args=(), device_types="cuda")
+def _op_agg_dense_id(x: Tensor, W: Tensor, W_id: Tensor, bias: Optional[Tensor], graph: int, id_index: Tensor,
+                     self_scale: float, relu: bool, want_P: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    return torch.ops.mp.agg_dense_id_raw(x, W, W_id, bias, graph, id_index, self_scale, relu, want_P)
+
+
+@_op_agg_dense_id.register_fake
+def _(x, W, W_id, bias, graph, id_index, self_scale, relu, want_P):
+    n = from_handle(graph).num_nodes
+    return (x.new_empty((n, W.size(1))), x.new_empty((n, x.size(1)) if want_P else (0,)),
+            x.new_empty((id_index.numel(), x.size(1))))
+
+
+def _agg_dense_id_setup(ctx, inputs, output):
+    x, W, W_id, bias, graph, id_index, self_scale, relu, want_P = inputs
+    out, P, x_id = output
+    ctx.graph, ctx.g_alive = graph, from_handle(graph)
+    ctx.self_scale, ctx.relu, ctx.has_bias, ctx.want_P = self_scale, relu, bias is not None, want_P
+    ctx.save_for_backward(P, W, W_id, x_id, id_index, out if relu else None, None if want_P else x)
+
+
+def _agg_dense_id_backward(ctx, gout, _gP, _gxid):
+    P, W, W_id, x_id, id_index, out, x = ctx.saved_tensors
+    gm = gout.contiguous()
+    if ctx.relu:
+        gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
+    need = ctx.needs_input_grad
+    if not ctx.want_P and need[1]:
+        P = torch.ops.mp.spmm_raw(x, ctx.graph, 0, _lib.SUM, x if ctx.self_scale != 0.0 else None, ctx.self_scale,
+                                  None, False, False)[0]
+    dW, db = torch.ops.mp.dense_wgrad_raw(P, gm, need[1], ctx.has_bias and need[3]) if (need[1] or need[3]) else (None, None)
+    # identity branch: T = A_id^T g [n_id, d_out];  dW_id = x_id^T T ;  dx[id] += T W_id^T
+    T = torch.ops.mp.id_branch_t_raw(gm, ctx.graph, id_index) if (need[0] or need[2]) else None
+    dWid = torch.mm(x_id.t(), T) if need[2] else None
+    dx = None
+    if need[0]:
+        dx = torch.ops.mp.agg_dense_raw(gm, W.t().contiguous(), None, ctx.graph, 1, _lib.SUM,
+                                        gm if ctx.self_scale != 0.0 else None, ctx.self_scale, False, False)[0]
+        dx = dx.index_add(0, id_index.to(torch.int64), torch.mm(T, W_id.t()))
+    return dx, _none_if_empty(dW), dWid, _none_if_empty(db), None, None, None, None, None
+
+
+register_autograd("mp::agg_dense_id", _agg_dense_id_backward, setup_context=_agg_dense_id_setup)
+
+
+def agg_dense_id(g, x, W, W_id, id_index, bias=None, relu=False, self_scale=0.0):
+    """act(A (x W + S x W_id) + bias) with S selecting the identity nodes' rows (torch.ops.mp.agg_dense_id): one
+    aggregate -> transform launch plus the identity branch's small product and row fix-up; None when the shapes are
+    outside the one-kernel layer (the caller then runs idgnn_aggregate + dense_fused)"""
+    _require_hip(x, "x")
+    if not (agg_dense_supported(g, x, W) and x.dtype == torch.float32 and g.num_cols == g.num_nodes):
+        return None
+    want_P = torch.is_grad_enabled() and W.requires_grad
+    return torch.ops.mp.agg_dense_id(x, W, W_id, bias, g.handle, id_index, float(self_scale), bool(relu), want_P)[0]
