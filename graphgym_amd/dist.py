@@ -74,43 +74,151 @@ def all_reduce_sum(value, device):
 
 
 class GradBucket:
-    """One flat fp32 bucket holding every parameter's gradient, all-reduced once per step.
+    """Flat fp32 gradient buckets, all-reduced once per step.
 
-    The models on this path are small (0.2 M - 3.3 M parameters, <= 13 MB): a single
-    bucket keeps the all-reduce at one RCCL launch, latency-bound either way."""
+    The models on this path are small (0.2 M - 3.3 M parameters, <= 13 MB): the exchange is latency-bound over xGMI,
+    so the point is to take it off the critical path, not to shrink it.  Two ways to use it:
 
-    def __init__(self, params):
+    * ``attach()`` (the data-parallel step of bench.py --mode step): every ``p.grad`` becomes a VIEW into a bucket
+      (no copy in or out), buckets follow reverse parameter order (the order backward produces gradients), and a
+      post-accumulate hook launches a bucket's all-reduce asynchronously the moment its last gradient is written —
+      the head's and the last layers' gradients travel while the first layers are still in backward.  ``finish()``
+      waits and scales.  Use ``zero_grad()`` of the bucket (the views must survive).
+    * ``all_reduce_mean()`` / ``all_reduce_sum()``: the synchronous form for an arbitrary loop (copies p.grad in and
+      out).
+
+    Averaging per-rank MEAN losses over ranks is a mean of means — not the full-batch gradient when shards hold
+    different numbers of labelled nodes (LPT balances stored entries, not labels).  Normalise the loss by the GLOBAL
+    count (``global_count``) and sum, as bench.py --mode step and tests/test_ddp_gpu.py do.
+    The RCCL ("nccl") branch has run on CPU/gloo and on one GPU shared by two gloo ranks only: no multi-GPU node was
+    available to this build."""
+
+    def __init__(self, params, n_buckets=1):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.views = []
-        off = 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        order = list(reversed(self.params))                       # backward produces gradients roughly in this order
+        n_buckets = max(1, min(int(n_buckets), len(order) or 1))
+        total = sum(p.numel() for p in order)
+        self.buckets = []                                          # (flat, [(param, view)])
+        cur, cur_n, target = [], 0, (total + n_buckets - 1) // n_buckets
+        groups = []
+        for p in order:
+            if cur and cur_n + p.numel() > target and len(groups) < n_buckets - 1:
+                groups.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            groups.append(cur)
+        for grp in groups:
+            flat = torch.zeros(sum(p.numel() for p in grp), dtype=torch.float32, device=dev)
+            views, off = [], 0
+            for p in grp:
+                views.append((p, flat[off:off + p.numel()].view_as(p)))
+                off += p.numel()
+            self.buckets.append((flat, views))
+        self.flat = self.buckets[0][0] if len(self.buckets) == 1 else None     # (kept for callers of the one-bucket form)
+        self._attached = False
+        self._pending = []
+        self._left = []
+        self._hooks = []
+
+    @staticmethod
+    def _active():
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _reduce(self, flat, async_op):
+        if dist.get_backend() == "gloo" and flat.is_cuda:   # rehearsal mode (ranks sharing a GPU): stage through the host
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+            return None
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    # ---- overlapped form ---------------------------------------------------------------
+    def attach(self):
+        """make every p.grad a view of its bucket and launch a bucket's all-reduce from the hook of its last gradient"""
+        if self._attached:
+            return self
+        for bi, (flat, views) in enumerate(self.buckets):
+            for p, v in views:
+                p.grad = v
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self._attached = True
+        self._reset()
+        return self
+
+    def _reset(self):
+        self._left = [len(views) for _, views in self.buckets]
+        self._pending = []
+
+    def _make_hook(self, bi):
+        def hook(param):
+            self._left[bi] -= 1
+            if self._left[bi] == 0 and self._active():
+                flat = self.buckets[bi][0]
+                if flat.is_cuda and dist.get_backend() != "gloo":
+                    # the gradient kernels run on the current stream; the collective is enqueued behind them by
+                    # torch.distributed's own stream hand-off and overlaps the backward kernels that follow
+                    self._pending.append(self._reduce(flat, async_op=True))
+                else:
+                    self._pending.append(self._reduce(flat, async_op=False))
+        return hook
+
+    def zero_grad(self):
+        for flat, _ in self.buckets:
+            flat.zero_()
+        self._reset()
+
+    def finish(self, scale=1.0):
+        """wait for the launched all-reduces (launch any bucket whose hooks did not all fire: parameters unused this
+        step), then multiply by `scale` (1 / world for a mean of per-rank gradients; 1 for globally normalised losses)"""
+        if self._active():
+            for bi, left in enumerate(self._left):
+                if left > 0:
+                    self._pending.append(self._reduce(self.buckets[bi][0], async_op=False))
+            for w in self._pending:
+                if w is not None:
+                    w.wait()
+        if scale != 1.0:
+            for flat, _ in self.buckets:
+                flat.mul_(scale)
+        self._reset()
+
+    # ---- synchronous form ----------------------------------------------------------------
+    def _sync_reduce(self, scale):
+        if not self._active():
+            return
+        for flat, views in self.buckets:
+            if not self._attached:
+                for p, v in views:
+                    if p.grad is None:
+                        v.zero_()
+                    else:
+                        v.copy_(p.grad)
+            self._reduce(flat, async_op=False)
+            if scale != 1.0:
+                flat.mul_(scale)
+            if not self._attached:
+                for p, v in views:
+                    if p.grad is None:
+                        p.grad = v.clone()
+                    else:
+                        p.grad.copy_(v)
 
     def all_reduce_mean(self):
         """average gradients over ranks in place (no-op for a single process)"""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad)
-        if dist.get_backend() == "gloo" and self.flat.is_cuda:   # rehearsal mode: stage through the host
-            host = self.flat.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            self.flat.copy_(host)
-        else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(dist.get_world_size())
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+        self._sync_reduce(1.0 / dist.get_world_size() if self._active() else 1.0)
+
+    def all_reduce_sum(self):
+        """sum gradients over ranks in place: the exact full-batch gradient when every rank's loss is normalised by
+        the global count (global_count)"""
+        self._sync_reduce(1.0)
+
+
+def global_count(local_count, device):
+    """sum of a per-rank count over ranks (e.g. labelled nodes), as a float"""
+    return all_reduce_sum(local_count, device)
 
 
 # ---- one graph partitioned by destination rows (SURVEY §8e, "one giant graph") ----------------
@@ -160,11 +268,22 @@ def _scatter_sum_rows(part, full):
     """sum of [N, d] partials over ranks, each rank keeping its own rows (reduce-scatter)"""
     if part.world == 1:
         return full
-    host = dist.get_backend() == "gloo" and full.is_cuda
-    t = full.cpu() if host else full.contiguous()
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)     # RCCL: reduce_scatter_tensor would move 1/world of this
     r0, r1 = part.rows
-    return t[r0:r1].to(full.device)
+    if dist.get_backend() == "gloo":             # gloo has no reduce_scatter_tensor: all-reduce (staged through the host)
+        host = full.is_cuda
+        t = full.cpu() if host else full.contiguous()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t[r0:r1].to(full.device)
+    # RCCL: every rank receives only its own rows (1 / world of the all-reduce's traffic).  reduce_scatter_tensor
+    # wants equal chunks: rows are padded to the widest range.
+    d = full.size(1)
+    inp = torch.zeros((part.world, part.max_rows, d), dtype=full.dtype, device=full.device)
+    for p in range(part.world):
+        a, b = part.bounds[p], part.bounds[p + 1]
+        inp[p, :b - a] = full[a:b]
+    out = torch.empty((part.max_rows, d), dtype=full.dtype, device=full.device)
+    dist.reduce_scatter_tensor(out, inp.view(-1, d), op=dist.ReduceOp.SUM)
+    return out[:r1 - r0]
 
 
 class _HaloAggregate(torch.autograd.Function):

@@ -184,12 +184,15 @@ class GCNIDConvLayer(nn.Module, _CachedEdgesMixin):
 
     _agg = "add"
 
-    def forward(self, x, edge_index, id, edge_weight=None, holder=None):
+    def graph_for(self, x, edge_index, edge_weight=None, holder=None):
+        """the normalised operator this layer aggregates with (cached on the batch)"""
         if self.normalize:
-            g = self._graph(holder, edge_index, x.size(0), edge_weight, loops="remaining", norm="col",
-                            fill=2.0 if self.improved else 1.0)
-        else:
-            g = self._graph(holder, edge_index, x.size(0), edge_weight, loops="none")
+            return self._graph(holder, edge_index, x.size(0), edge_weight, loops="remaining", norm="col",
+                               fill=2.0 if self.improved else 1.0)
+        return self._graph(holder, edge_index, x.size(0), edge_weight, loops="none")
+
+    def forward(self, x, edge_index, id, edge_weight=None, holder=None):
+        g = self.graph_for(x, edge_index, edge_weight, holder)
         order = _pick_order(self.order, self.in_channels, self.out_channels)
         if order == "aggregate_first" and self._agg in ("add", "sum"):
             out = ops.agg_dense_id(g, x, self.weight, self.weight_id, id, self.bias)   # one launch + the identity fix-up
@@ -419,9 +422,12 @@ class GCNConvLayer(nn.Module):
         glorot(self.weight)
         zeros(self.bias)
 
+    def graph_for(self, x, edge_index, edge_weight=None, holder=None):
+        return get_graph(holder, edge_index, x.size(0), loops="remaining", norm="row",
+                         fill=2.0 if self.improved else 1.0, edge_weight=edge_weight)
+
     def forward(self, x, edge_index, edge_weight=None, holder=None):
-        g = get_graph(holder, edge_index, x.size(0), loops="remaining", norm="row",
-                      fill=2.0 if self.improved else 1.0, edge_weight=edge_weight)
+        g = self.graph_for(x, edge_index, edge_weight, holder)
         if _pick_order(self.order, self.in_channels, self.out_channels) == "aggregate_first":
             return ops.agg_dense(g, x, self.weight, bias=self.bias)
         return ops.spmm(g, ops.dense_fused(x, self.weight), "sum", bias=self.bias)

@@ -1,0 +1,149 @@
+"""graphgym_plugin.accelerate(model): the post-ops GraphGym builds INSIDE its layer wrapper
+(graphgym/models/layer.py:16-47: conv -> BatchNorm1d -> [Dropout] -> act -> [row L2-normalise]; stage-level
+normalisation gnn.py:79-80) moved onto the engine for an already-built model.
+
+The wrapper below restates the reference's GeneralLayer with plain torch modules (what create_model() produces when
+the engine's conv classes sit in layer_dict); the oracle side restates the same arithmetic on the CPU in float64."""
+import types
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from _tol import assert_close_all, assert_close_rows
+
+
+class RefStyleGeneralLayer(nn.Module):
+    """layer.py:16-47 as written in the reference (has_bn / has_act / has_l2norm, bias = not has_bn)"""
+
+    def __init__(self, conv_cls, dim_in, dim_out, has_act=True, has_bn=True, has_l2norm=False, eps=1e-5, mom=0.1):
+        super().__init__()
+        self.has_l2norm = has_l2norm
+        self.layer = conv_cls(dim_in, dim_out, bias=not has_bn)
+        wrapper = []
+        if has_bn:
+            wrapper.append(nn.BatchNorm1d(dim_out, eps=eps, momentum=mom))
+        if has_act:
+            wrapper.append(nn.ReLU())
+        self.post_layer = nn.Sequential(*wrapper)
+
+    def forward(self, batch):
+        batch = self.layer(batch)
+        batch.node_feature = self.post_layer(batch.node_feature)
+        if self.has_l2norm:
+            batch.node_feature = F.normalize(batch.node_feature, p=2, dim=1)
+        return batch
+
+
+def test_accelerate_swaps_in_place_and_keeps_the_state_dict():
+    import graphgym_amd.graphgym_plugin as plugin
+    from graphgym_amd import layers as L, nn as mpnn
+    model = nn.Sequential(RefStyleGeneralLayer(L.GCNConv, 8, 16, has_l2norm=True),
+                          RefStyleGeneralLayer(L.GCNIDConv, 16, 16, has_bn=False))
+    keys = list(model.state_dict().keys())
+    bn = model[0].post_layer[0]
+    w, rm = bn.weight, bn.running_mean
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    assert plugin.accelerate(model) == 2
+    new = model[0].post_layer[0]
+    assert isinstance(new, mpnn.BatchNorm1d) and new.relu is True and isinstance(model[0].post_layer[1], nn.Identity)
+    assert new.weight is w and new.running_mean is rm                       # the same objects: optimizers keep working
+    assert any(p is w for grp in opt.param_groups for p in grp["params"])
+    assert list(model.state_dict().keys()) == keys
+    assert isinstance(model[1].post_layer[0], nn.ReLU)                       # no BatchNorm: nothing to fuse into
+    assert plugin.accelerate(model) == 2                                     # idempotent
+    assert isinstance(model[0].post_layer[0], mpnn.BatchNorm1d)
+
+
+def _graph(n, gen):
+    ei = torch.randint(0, n, (2, 6 * n), generator=gen)
+    ei = ei[:, ei[0] != ei[1]]
+    return torch.cat([ei, ei.flip(0)], 1)
+
+
+def _oracle_general_layer(kind, x, ei, ids, W, Wid, bias, bn, training, has_l2norm):
+    """conv (oracle/ref_layers) -> BatchNorm1d -> ReLU -> F.normalize, float64"""
+    from oracle import ref_layers as RL
+    torch.set_default_dtype(torch.float64)
+    try:
+        if kind == "gcnconv":
+            h = RL.pyg_gcn_conv(x, ei, W, bias)
+        else:
+            h = RL.gcnid_conv(x, ei, ids, W, Wid, bias)
+        if bn is not None:
+            gamma, beta, rmean, rvar, eps = bn
+            if training:
+                mean, var = h.mean(0), h.var(0, unbiased=False)
+            else:
+                mean, var = rmean, rvar
+            h = (h - mean) / torch.sqrt(var + eps) * gamma + beta
+        h = torch.relu(h)
+        return F.normalize(h, p=2, dim=1) if has_l2norm else h
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,has_bn,has_l2norm", [("gcnconv", True, True), ("gcnidconv", True, False),
+                                                    ("gcnconv", False, True), ("gcnidconv", False, False)])
+def test_accelerated_layer_matches_the_oracle_train_and_eval(dev, kind, has_bn, has_l2norm):
+    import graphgym_amd.graphgym_plugin as plugin
+    from graphgym_amd import layers as L, ops
+    gen = torch.Generator().manual_seed(5)
+    n, F_in, d = 700, 64, 64
+    ei = _graph(n, gen)
+    x = torch.randn(n, F_in, generator=gen)
+    ids = torch.arange(0, n, 13)
+    cls = L.GCNConv if kind == "gcnconv" else L.GCNIDConv
+    torch.manual_seed(3)
+    layer = RefStyleGeneralLayer(cls, F_in, d, has_bn=has_bn, has_l2norm=has_l2norm).to(dev)
+    if has_bn:
+        with torch.no_grad():
+            layer.post_layer[0].weight.uniform_(0.5, 1.5)
+            layer.post_layer[0].bias.uniform_(-0.3, 0.3)
+    assert plugin.accelerate(layer) == 1
+    conv = layer.layer.model
+    W = conv.weight.detach().cpu().double()
+    Wid = conv.weight_id.detach().cpu().double() if kind == "gcnidconv" else None
+    bias = None if conv.bias is None else conv.bias.detach().cpu().double()
+
+    def bn_state():
+        if not has_bn:
+            return None
+        b = layer.post_layer[0]
+        return (b.weight.detach().cpu().double(), b.bias.detach().cpu().double(), b.running_mean.cpu().double(),
+                b.running_var.cpu().double(), b.eps)
+
+    # ---- training step: batch statistics, running statistics updated, gradients ----
+    layer.train()
+    batch = types.SimpleNamespace(node_feature=x.to(dev).requires_grad_(True), edge_index=ei.to(dev),
+                                  node_id_index=ids.to(dev))
+    xin = batch.node_feature
+    out = layer(batch).node_feature
+    up = torch.randn(n, d, generator=gen)
+    out.backward(up.to(dev))
+    xr = x.double().requires_grad_(True)
+    Wr = W.clone().requires_grad_(True)
+    ref = _oracle_general_layer(kind, xr, ei, ids, Wr, Wid, bias, bn_state(), True, has_l2norm)
+    ref.backward(up.double())
+    assert_close_rows(out, ref.detach(), 1e-5, what="train out")
+    assert_close_rows(xin.grad, xr.grad, 2e-5, what="train dx")
+    assert_close_all(conv.weight.grad, Wr.grad, 2e-5, what="train dW")
+    if has_bn:
+        b = layer.post_layer[0]
+        assert int(b.num_batches_tracked) == 1 and float((b.running_mean.abs()).max()) > 0
+    # ---- eval: running statistics, everything folded into the aggregation's flush ----
+    layer.eval()
+    calls = []
+    orig = ops.spmm_fused_eval
+    ops.spmm_fused_eval = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            batch = types.SimpleNamespace(node_feature=x.to(dev), edge_index=ei.to(dev), node_id_index=ids.to(dev))
+            out = layer(batch).node_feature
+    finally:
+        ops.spmm_fused_eval = orig
+    assert len(calls) == 1                                                   # one aggregation launch carries the post-ops
+    ref = _oracle_general_layer(kind, x.double(), ei, ids, W, Wid, bias, bn_state(), False, has_l2norm)
+    assert_close_rows(out, ref, 1e-5, what="eval out")

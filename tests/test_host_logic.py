@@ -148,3 +148,43 @@ def test_order_choice_and_fused_shape_gate(monkeypatch):
     assert not ops.agg_dense_supported(types.SimpleNamespace(nnz=10, max_row_entries=lambda: 1 << 20), x, W)   # star-like hub
     monkeypatch.setenv("MP_FUSED", "0")
     assert not ops.agg_dense_supported(g, x, W)
+
+
+def _overlap_worker(rank, world, port, out):
+    """two ranks with different numbers of labelled examples: globally normalised losses + the overlapped two-bucket
+    exchange give the full-batch gradient on every rank (a mean of per-rank mean losses would not)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from graphgym_amd import dist as D
+    D.init_from_env("cpu")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(10, 6, generator=g), torch.randint(0, 3, (10,), generator=g)
+    lo, hi = (0, 7) if rank == 0 else (7, 10)                        # 7 examples on rank 0, 3 on rank 1
+    total = D.global_count(hi - lo, torch.device("cpu"))
+    bucket = D.GradBucket(model.parameters(), n_buckets=2).attach()
+    assert len(bucket.buckets) == 2 and all(p.grad is not None for p in model.parameters())
+    for _ in range(2):                                               # second step: views survive zero_grad
+        bucket.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(X[lo:hi]), Y[lo:hi], reduction="sum") / total
+        loss.backward()
+        bucket.finish(1.0)
+    torch.save({"grads": [p.grad.clone() for p in model.parameters()], "total": total},
+               os.path.join(out, f"o{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_overlapped_buckets_give_the_full_batch_gradient_gloo_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(tmp_path / "o0.pt", weights_only=True)
+    b = torch.load(tmp_path / "o1.pt", weights_only=True)
+    assert a["total"] == 10.0
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(10, 6, generator=g), torch.randint(0, 3, (10,), generator=g)
+    torch.nn.functional.cross_entropy(model(X), Y, reduction="mean").backward()
+    for p, ga, gb in zip(model.parameters(), a["grads"], b["grads"]):
+        assert torch.allclose(ga, p.grad, atol=1e-6) and torch.equal(ga, gb)
