@@ -147,10 +147,11 @@ def run_aggregate(args, rank, world, dev):
     if x is None:
         x = torch.empty((n, d), dtype=torch.float32, device=dev)
     x.uniform_(-1.0, 1.0, generator=gen)
-    y = placement.empty_or_torch((n, d), dev, reads=(x,))
+    y = placement.empty_or_torch((n, d), dev, reads=(x,), verify=4)    # resident output: the 4 best predicted positions timed once
     ar = placement.arena(dev, create=False)
     place = {"engine_placed": bool(ar is not None and ar.owns(y)), "x_in_arena": bool(x_engine),
              "predicted_conflict": getattr(y, "_mp_predicted_conflict", None),
+             "verified_candidates_ms": getattr(y, "_mp_verified_candidates_ms", None),
              "arena": None if ar is None else ar.stats()}
 
     def step():

@@ -6,10 +6,11 @@
 //   GCNIDConvLayer.norm                     idconv.py:132-148
 //   add_remaining_self_loops / remove_self_loops / add_self_loops
 //                                           idconv.py:52,140,232,302-304,370
-// The sort is rocPRIM's device radix sort (through the hipCUB front end): it is a
+// The sort is rocPRIM's device radix sort (rocprim::radix_sort_pairs, called directly): a
 // once-per-graph preprocessing step, not the hot path; everything around it is ours.
 #include "common.h"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace mp {
 
@@ -29,10 +30,10 @@ struct CooWs {
 
 static int coo_ws_layout(int64_t M, int64_t N, void* base, CooWs* w) {
   size_t cub_bytes = 0;
-  hipcub::DoubleBuffer<uint64_t> dk(nullptr, nullptr);
-  hipcub::DoubleBuffer<uint32_t> dv(nullptr, nullptr);
-  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, dk, dv, (int)M, 0, 64, 0);
-  if (e != hipSuccess) { set_hip_error(e, "hipcub::DeviceRadixSort::SortPairs(size query)"); return MP_ERR_HIP; }
+  rocprim::double_buffer<uint64_t> dk(nullptr, nullptr);
+  rocprim::double_buffer<uint32_t> dv(nullptr, nullptr);
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, cub_bytes, dk, dv, (size_t)M, 0u, 64u, (hipStream_t)0);
+  if (e != hipSuccess) { set_hip_error(e, "rocprim::radix_sort_pairs(size query)"); return MP_ERR_HIP; }
   char* p = (char*)base;
   size_t off = 0;
   auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes, 256); return r; };
@@ -350,14 +351,14 @@ int mp_csr_from_coo(const int64_t* dst, const int64_t* src, const float* w, int6
   hipLaunchKernelGGL(coo_keys_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, dst, src, w, E, N, flags,
                      L.keys_a, L.pay_a, L.loop_w);
   MP_LAUNCH_CHECK();
-  hipcub::DoubleBuffer<uint64_t> dk(L.keys_a, L.keys_b);
-  hipcub::DoubleBuffer<uint32_t> dv(L.pay_a, L.pay_b);
+  rocprim::double_buffer<uint64_t> dk(L.keys_a, L.keys_b);
+  rocprim::double_buffer<uint32_t> dv(L.pay_a, L.pay_b);
   size_t cub_bytes = L.cub_bytes;
-  MP_HIP(hipcub::DeviceRadixSort::SortPairs(L.cub, cub_bytes, dk, dv, (int)M, 0, key_bits(N), st));
-  hipLaunchKernelGGL(rowptr_from_keys_kernel, dim3(flat_grid(N + 1)), dim3(kBlock), 0, st, dk.Current(),
+  MP_HIP(rocprim::radix_sort_pairs(L.cub, cub_bytes, dk, dv, (size_t)M, 0u, (unsigned)key_bits(N), st));
+  hipLaunchKernelGGL(rowptr_from_keys_kernel, dim3(flat_grid(N + 1)), dim3(kBlock), 0, st, dk.current(),
                      M, N, rowptr);
   MP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(coo_emit_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, dk.Current(), dv.Current(),
+  hipLaunchKernelGGL(coo_emit_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, dk.current(), dv.current(),
                      w, L.loop_w, M, E, N, fill, keep ? 1 : 0, col, val, eid);
   MP_LAUNCH_CHECK();
   return MP_OK;
@@ -412,15 +413,15 @@ int mp_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val
   hipLaunchKernelGGL(transpose_keys_kernel, dim3(flat_grid(nnz)), dim3(kBlock), 0, st, rowptr, col,
                      (int32_t)n_rows, nnz, L.keys_a, L.pay_a);
   MP_LAUNCH_CHECK();
-  hipcub::DoubleBuffer<uint64_t> dk(L.keys_a, L.keys_b);
-  hipcub::DoubleBuffer<uint32_t> dv(L.pay_a, L.pay_b);
+  rocprim::double_buffer<uint64_t> dk(L.keys_a, L.keys_b);
+  rocprim::double_buffer<uint32_t> dv(L.pay_a, L.pay_b);
   size_t cub_bytes = L.cub_bytes;
-  MP_HIP(hipcub::DeviceRadixSort::SortPairs(L.cub, cub_bytes, dk, dv, (int)nnz, 0, key_bits(N), st));
-  hipLaunchKernelGGL(rowptr_from_keys_kernel, dim3(flat_grid(N + 1)), dim3(kBlock), 0, st, dk.Current(),
+  MP_HIP(rocprim::radix_sort_pairs(L.cub, cub_bytes, dk, dv, (size_t)nnz, 0u, (unsigned)key_bits(N), st));
+  hipLaunchKernelGGL(rowptr_from_keys_kernel, dim3(flat_grid(N + 1)), dim3(kBlock), 0, st, dk.current(),
                      nnz, N, t_rowptr);
   MP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(transpose_emit_kernel, dim3(flat_grid(nnz)), dim3(kBlock), 0, st, dk.Current(),
-                     dv.Current(), val, nnz, t_col, t_val, pos);
+  hipLaunchKernelGGL(transpose_emit_kernel, dim3(flat_grid(nnz)), dim3(kBlock), 0, st, dk.current(),
+                     dv.current(), val, nnz, t_col, t_val, pos);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

@@ -163,9 +163,14 @@ __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(co
 // 32 consecutive words.  Split-K over nodes: a block owns `chunk` rows and one 128 x 128 output tile and
 // writes its partial to a slab; a second kernel adds the slabs in chunk order (bitwise reproducible, unlike
 // float atomics).
-template <bool VEC>
+// RELU: the backward of a ReLU epilogue rides along — g is masked by [Y > 0] (Y = the forward output) on its way to
+// LDS, and the blocks of the first f-tile also write the masked gradient GM (what the input-gradient launch reads):
+// the separate masking pass (30 GB at 10^7 x 256) disappears into a pass that is bound by its MFMA work.
+template <bool VEC, bool RELU>
 __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __restrict__ P, int64_t ldp,
-                                                                const float* __restrict__ G, int64_t ldg,
+                                                                const float* G, int64_t ldg,
+                                                                const float* __restrict__ Y, int64_t ldy,
+                                                                float* GM, int64_t ldgm,
                                                                 int64_t M, int32_t F, int32_t d, int64_t chunk,
                                                                 float* __restrict__ slabs,
                                                                 float* __restrict__ bias_slabs) {
@@ -195,11 +200,33 @@ __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __r
       rp[1] = (ok && f0 + l_col + 4 < F) ? *reinterpret_cast<const f32x4*>(ps + 4) : z;
       rg[0] = (ok && d0 + l_col < d) ? *reinterpret_cast<const f32x4*>(gs) : z;
       rg[1] = (ok && d0 + l_col + 4 < d) ? *reinterpret_cast<const f32x4*>(gs + 4) : z;
+      if constexpr (RELU) {
+        const float* ys = Y + m * ldy + d0 + l_col;
+        const f32x4 y0 = (ok && d0 + l_col < d) ? *reinterpret_cast<const f32x4*>(ys) : z;
+        const f32x4 y1 = (ok && d0 + l_col + 4 < d) ? *reinterpret_cast<const f32x4*>(ys + 4) : z;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          rg[0][i] = y0[i] > 0.f ? rg[0][i] : 0.f;
+          rg[1][i] = y1[i] > 0.f ? rg[1][i] : 0.f;
+        }
+        if (GM != nullptr && f0 == 0 && ok) {
+          float* go = GM + m * ldgm + d0 + l_col;
+          if (d0 + l_col < d) *reinterpret_cast<f32x4*>(go) = rg[0];
+          if (d0 + l_col + 4 < d) *reinterpret_cast<f32x4*>(go + 4) = rg[1];
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         rp[i >> 2][i & 3] = (ok && f0 + l_col + i < F) ? ps[i] : 0.f;
-        rg[i >> 2][i & 3] = (ok && d0 + l_col + i < d) ? gs[i] : 0.f;
+        float gv = (ok && d0 + l_col + i < d) ? gs[i] : 0.f;
+        if constexpr (RELU) {
+          const bool in = ok && d0 + l_col + i < d;
+          const float yv = in ? Y[m * ldy + d0 + l_col + i] : 0.f;
+          gv = yv > 0.f ? gv : 0.f;
+          if (GM != nullptr && f0 == 0 && in) GM[m * ldgm + d0 + l_col + i] = gv;
+        }
+        rg[i >> 2][i & 3] = gv;
       }
     }
   };
@@ -338,16 +365,19 @@ int mp_dense_wgrad_ws_bytes(int64_t M, int32_t F, int32_t d, size_t* bytes_host)
   return MP_OK;
 }
 
-int mp_dense_wgrad_f32(const float* P, int64_t ldp, const float* G, int64_t ldg, int64_t M, int32_t F,
-                       int32_t d, float* dW, float* dbias, void* ws, size_t ws_bytes, mp_stream_t stream) {
+static int wgrad_common(const float* P, int64_t ldp, const float* G, int64_t ldg, const float* Y, int64_t ldy,
+                        float* GM, int64_t ldgm, int64_t M, int32_t F, int32_t d, float* dW, float* dbias, void* ws,
+                        size_t ws_bytes, hipStream_t st) {
   if (M < 0 || F <= 0 || d <= 0 || !dW || (M > 0 && (!P || !G)) || ldp < F || ldg < d) return MP_ERR_INVALID_ARG;
-  hipStream_t st = as_stream(stream);
+  if (Y && ldy < d) return MP_ERR_INVALID_ARG;
+  if (GM && (!Y || ldgm < d)) return MP_ERR_INVALID_ARG;
   if (M == 0) {
     MP_HIP(hipMemsetAsync(dW, 0, (size_t)F * d * 4, st));
     if (dbias) MP_HIP(hipMemsetAsync(dbias, 0, (size_t)d * 4, st));
     return MP_OK;
   }
-  const bool vec = !(F % 4 || d % 4 || ldp % 4 || ldg % 4) && al16(P) && al16(G);
+  const bool vec = !(F % 4 || d % 4 || ldp % 4 || ldg % 4 || (Y && ldy % 4) || (GM && ldgm % 4)) && al16(P) &&
+                   al16(G) && al16(Y) && al16(GM);
   const int64_t chunk = wgrad_chunk(M);
   const int64_t n_chunk = ceil_div(M, chunk);
   const size_t need = (size_t)n_chunk * ((size_t)F * d + d) * 4;
@@ -355,12 +385,13 @@ int mp_dense_wgrad_f32(const float* P, int64_t ldp, const float* G, int64_t ldg,
   float* bias_slabs = dbias ? (float*)ws + (size_t)n_chunk * F * d : nullptr;
   const int64_t tiles = ceil_div(F, 128) * ceil_div(d, 128);
   if (tiles * n_chunk >= INT32_MAX) return MP_ERR_UNSUPPORTED;
-  if (vec)
-    hipLaunchKernelGGL((dense_wgrad_kernel<true>), dim3((unsigned)(tiles * n_chunk)), dim3(kBlock), 0, st, P, ldp, G,
-                       ldg, M, F, d, chunk, (float*)ws, bias_slabs);
-  else
-    hipLaunchKernelGGL((dense_wgrad_kernel<false>), dim3((unsigned)(tiles * n_chunk)), dim3(kBlock), 0, st, P, ldp, G,
-                       ldg, M, F, d, chunk, (float*)ws, bias_slabs);
+  const dim3 grid((unsigned)(tiles * n_chunk));
+#define MP_WGRAD(VECV, RELUV)                                                                                     \
+  hipLaunchKernelGGL((dense_wgrad_kernel<VECV, RELUV>), grid, dim3(kBlock), 0, st, P, ldp, G, ldg, Y, ldy, GM, ldgm, M, \
+                     F, d, chunk, (float*)ws, bias_slabs)
+  if (Y) { if (vec) MP_WGRAD(true, true); else MP_WGRAD(false, true); }
+  else { if (vec) MP_WGRAD(true, false); else MP_WGRAD(false, false); }
+#undef MP_WGRAD
   MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)F * d)), dim3(kBlock), 0, st, (const float*)ws,
                      n_chunk, (int64_t)F * d, dW);
@@ -371,6 +402,18 @@ int mp_dense_wgrad_f32(const float* P, int64_t ldp, const float* G, int64_t ldg,
     MP_LAUNCH_CHECK();
   }
   return MP_OK;
+}
+
+int mp_dense_wgrad_f32(const float* P, int64_t ldp, const float* G, int64_t ldg, int64_t M, int32_t F,
+                       int32_t d, float* dW, float* dbias, void* ws, size_t ws_bytes, mp_stream_t stream) {
+  return wgrad_common(P, ldp, G, ldg, nullptr, 0, nullptr, 0, M, F, d, dW, dbias, ws, ws_bytes, as_stream(stream));
+}
+
+int mp_dense_wgrad_relu_f32(const float* P, int64_t ldp, const float* G, int64_t ldg, const float* Y, int64_t ldy,
+                            float* GM, int64_t ldgm, int64_t M, int32_t F, int32_t d, float* dW, float* dbias,
+                            void* ws, size_t ws_bytes, mp_stream_t stream) {
+  if (!Y) return MP_ERR_INVALID_ARG;
+  return wgrad_common(P, ldp, G, ldg, Y, ldy, GM, ldgm, M, F, d, dW, dbias, ws, ws_bytes, as_stream(stream));
 }
 
 }  // extern "C"

@@ -61,12 +61,13 @@ class CSRGraph:
     @classmethod
     def from_edge_index(cls, edge_index, num_nodes, edge_weight=None, *, dst_row=1,
                         remove_self_loops=False, add_self_loops=False, keep_loop_weight=False,
-                        fill=1.0, validate=True):
+                        fill=1.0, validate=True, num_cols=None):
         """edge_index: LongTensor [2, E] on the GPU.  dst_row=1 is PyG's
         source_to_target flow (edge_index[1] = destination i); dst_row=0 is the
         TF path's SparseAdj convention (edge_index[0] = row = destination).
         validate (default): node ids outside [0, num_nodes) raise ValueError, as indexing does in the reference,
-        instead of becoming out-of-range column indices for the kernels (one E-sized pass; the CSR is cached per batch)."""
+        instead of becoming out-of-range column indices for the kernels (one E-sized pass; the CSR is cached per batch).
+        num_cols: number of source nodes of a rectangular operator (pooling: rows = graphs, columns = nodes)."""
         _require_hip(edge_index, "edge_index")
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError("edge_index must be [2, E]")
@@ -84,11 +85,15 @@ class CSRGraph:
                 (_lib.COO_ADD_SELF_LOOPS if add_self_loops else 0) | \
                 (_lib.COO_KEEP_LOOP_WEIGHT if keep_loop_weight else 0)
         with torch.cuda.device(dev):
+            NC = N if num_cols is None else int(num_cols)
+            if NC != N and (remove_self_loops or add_self_loops):
+                raise ValueError("self-loop edits need a square operator")
             if validate:
-                bad = torch.zeros(1, dtype=torch.int32, device=dev)
-                check(L.mp_check_edge_index(ptr(dst), ptr(src), E, N, ptr(bad), _stream()))
-                if int(bad.item()):
-                    raise ValueError(f"edge_index has {int(bad.item())} entries outside [0, {N})")
+                bad = torch.zeros(2, dtype=torch.int32, device=dev)
+                check(L.mp_check_edge_index(ptr(dst), ptr(dst), E, N, ptr(bad[0:1]), _stream()))
+                check(L.mp_check_edge_index(ptr(src), ptr(src), E, NC, ptr(bad[1:2]), _stream()))
+                if int(bad.sum().item()):
+                    raise ValueError(f"edge_index has entries outside [0, {N}) x [0, {NC})")
             cap = E + (N if add_self_loops else 0)
             need = C.c_size_t(0)
             check(L.mp_csr_from_coo_ws_bytes(E, N, C.byref(need)))
@@ -102,7 +107,7 @@ class CSRGraph:
                                     ptr(col), ptr(val), ptr(eid), ptr(ws), need.value, _stream()),
                   "mp_csr_from_coo")
             nnz = int(rowptr[N].item())
-        g = cls(rowptr, col[:nnz], None if val is None else val[:nnz], eid[:nnz], N, nnz)
+        g = cls(rowptr, col[:nnz], None if val is None else val[:nnz], eid[:nnz], N, nnz, num_cols)
         return g
 
     @classmethod
@@ -272,13 +277,18 @@ class CSRGraph:
         return self._t_mean
 
     def degree(self, axis="row"):
+        """weighted degree by destination ('row': SparseAdj.reduce_sum(axis=-1), sparse_adj.py:84-85) or by source
+        ('col': scatter_add(edge_weight, edge_index[0]), idconv.py:56,144).  Both are row sums in a fixed order (the
+        by-source sum runs over the cached transposed CSR): bitwise reproducible, no float atomics."""
         L = lib()
-        if axis != "row" and self.num_cols != self.num_nodes:
-            raise ValueError("degree('col') needs a square operator")
+        if axis != "row":
+            if self.num_cols != self.num_nodes:
+                raise ValueError("degree('col') needs a square operator")
+            return self.transpose().degree("row")
         deg = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             check(L.mp_csr_degree(ptr(self.rowptr), ptr(self.col), ptr(self.val), self.num_nodes, self.nnz,
-                                  _lib.AXIS_ROW if axis == "row" else _lib.AXIS_COL, ptr(deg), _stream()))
+                                  _lib.AXIS_ROW, ptr(deg), _stream()))
         return deg
 
     def gcn_norm(self, deg_axis="row"):
@@ -286,12 +296,19 @@ class CSRGraph:
         deg_axis='row': degree by destination (TfgIDLayer.py:549); 'col': by source (idconv.py:143-144)."""
         L = lib()
         N, nnz, dev = self.num_nodes, self.nnz, self.device
+        if deg_axis != "row":
+            # by-source degrees from the transposed CSR's row sums (deterministic), then one scaling pass
+            deg = self.degree("col")
+            dinv = deg.pow(-0.5)
+            dinv = torch.where(torch.isfinite(dinv), dinv, torch.zeros_like(dinv))     # idconv.py:57-58,145-146
+            g = self.scaled(row_scale=dinv, col_scale=dinv)
+            g.dinv = dinv
+            return g
         val_out = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
         dinv = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             check(L.mp_gcn_norm_edges(ptr(self.rowptr), ptr(self.col), ptr(self.val), N, nnz,
-                                      _lib.AXIS_ROW if deg_axis == "row" else _lib.AXIS_COL,
-                                      ptr(val_out), ptr(dinv), _stream()), "mp_gcn_norm_edges")
+                                      _lib.AXIS_ROW, ptr(val_out), ptr(dinv), _stream()), "mp_gcn_norm_edges")
         g = self.with_values(val_out[:nnz])
         g.dinv = dinv[:N]
         return g

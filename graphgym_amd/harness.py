@@ -90,10 +90,9 @@ class TfgNodeModel(nn.Module):
 
 def tfg_loss(logits, node_label_index, labels, kernel_params, ego=False):
     """graphgym/loss.py:53-68"""
-    masked = logits[node_label_index]
     if ego:
         labels = labels[node_label_index]
-    ce = F.cross_entropy(masked, labels, reduction="mean")
+    ce = mpnn.softmax_cross_entropy(logits, labels, node_label_index)   # == F.cross_entropy(logits[idx], labels)
     l2 = sum((p * p).sum() / 2 for p in kernel_params)     # tf.nn.l2_loss = sum(t^2) / 2
     return ce + 5e-4 * l2
 

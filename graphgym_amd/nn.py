@@ -112,6 +112,79 @@ def _bn_backward(ctx, dy, _dmean, _dinvstd, _dvar):
 register_autograd("mp::bn_act", _bn_backward, setup_context=_bn_setup)
 
 
+# ---- softmax cross-entropy over the labelled rows (graphgym/loss.py:53-68, 20-37) -------------------------------
+@custom_op("mp::softmax_ce_rows_raw", mutates_args=(), device_types="cuda")
+def _op_ce_rows_raw(logits: Tensor, labels: Tensor, index: Optional[Tensor]) -> Tensor:
+    _require_hip(logits, "logits")
+    z = logits if (logits.dtype == torch.float32 and logits.stride(-1) == 1) else logits.float().contiguous()
+    y = labels.to(torch.int64).contiguous()
+    idx = None if index is None else index.to(torch.int64).contiguous()
+    n_sel = y.numel()
+    out = torch.empty(n_sel, dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        check(lib().mp_softmax_ce_rows_f32(ptr(z), z.stride(0), ptr(y), ptr(idx), n_sel, z.size(1), ptr(out), _stream()),
+              "mp_softmax_ce_rows_f32")
+    return out
+
+
+@_op_ce_rows_raw.register_fake
+def _(logits, labels, index):
+    return logits.new_empty((labels.numel(),), dtype=torch.float32)
+
+
+@custom_op("mp::softmax_ce_bwd_raw", mutates_args=(), device_types="cuda")
+def _op_ce_bwd_raw(logits: Tensor, labels: Tensor, index: Optional[Tensor], gscale: Tensor, inv_n: float) -> Tensor:
+    z = logits if (logits.dtype == torch.float32 and logits.stride(-1) == 1) else logits.float().contiguous()
+    y = labels.to(torch.int64).contiguous()
+    idx = None if index is None else index.to(torch.int64).contiguous()
+    g = gscale.to(torch.float32).reshape(1).contiguous()
+    d = torch.zeros_like(z) if idx is not None else torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        check(lib().mp_softmax_ce_bwd_f32(ptr(z), z.stride(0), ptr(y), ptr(idx), y.numel(), z.size(1), ptr(g),
+                                          float(inv_n), ptr(d), d.stride(0), _stream()), "mp_softmax_ce_bwd_f32")
+    return d
+
+
+@_op_ce_bwd_raw.register_fake
+def _(logits, labels, index, gscale, inv_n):
+    return logits.new_empty(logits.shape, dtype=torch.float32)
+
+
+@custom_op("mp::softmax_ce", mutates_args=(), device_types="cuda")
+def _op_softmax_ce(logits: Tensor, labels: Tensor, index: Optional[Tensor]) -> Tensor:
+    """mean over the labelled rows of softmax cross-entropy(logits[index], labels): one pass forward, one backward"""
+    return torch.ops.mp.softmax_ce_rows_raw(logits, labels, index).mean()
+
+
+@_op_softmax_ce.register_fake
+def _(logits, labels, index):
+    return logits.new_empty((), dtype=torch.float32)
+
+
+def _ce_setup(ctx, inputs, output):
+    logits, labels, index = inputs
+    ctx.save_for_backward(logits, labels, index)
+
+
+def _ce_backward(ctx, g):
+    logits, labels, index = ctx.saved_tensors
+    n = max(labels.numel(), 1)
+    return torch.ops.mp.softmax_ce_bwd_raw(logits, labels, index, g, 1.0 / n), None, None
+
+
+register_autograd("mp::softmax_ce", _ce_backward, setup_context=_ce_setup)
+
+
+def softmax_cross_entropy(logits, labels, index=None):
+    """F.cross_entropy(logits[index], labels, reduction='mean') on the engine (no gather copy, one pass each way);
+    small problems stay with torch"""
+    if (not logits.is_cuda or logits.dim() != 2 or labels.numel() * logits.size(1) < (1 << 20)
+            or logits.dtype != torch.float32):
+        sel = logits if index is None else logits[index]
+        return F.cross_entropy(sel, labels, reduction="mean")
+    return torch.ops.mp.softmax_ce(logits, labels, index)
+
+
 class BatchNorm1d(nn.BatchNorm1d):
     """``nn.BatchNorm1d`` whose training-mode forward / backward run on the engine; ``relu=True`` fuses the
     activation that follows it in GraphGym's layer wrapper.  Eval mode uses the running statistics (torch)."""

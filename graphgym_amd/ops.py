@@ -155,6 +155,28 @@ def _raw_dense_wgrad(P, G, want_bias=False):
     return (out, db) if want_bias else out
 
 
+def _raw_dense_wgrad_relu(P, G, Y, want_bias=False):
+    """(P^T (G * [Y > 0]), its column sums or None, G * [Y > 0]) in one pass (mp_dense_wgrad_relu_f32): the weight-gradient
+    kernel masks the incoming gradient by the forward's ReLU pattern as it reads it and writes the masked gradient out
+    for the input-gradient launch; None when the shape is outside the kernel"""
+    L = lib()
+    M, F = P.shape
+    d = G.size(1)
+    out = torch.empty((F, d), dtype=torch.float32, device=P.device)
+    db = torch.empty(d, dtype=torch.float32, device=P.device) if want_bias else None
+    gm = placement.empty_or_torch((M, d), P.device, reads=(G, Y, P))
+    with torch.cuda.device(P.device):
+        nb = C.c_size_t(0)
+        check(L.mp_dense_wgrad_ws_bytes(M, F, d, C.byref(nb)))
+        ws = torch.empty(max(nb.value, 1), dtype=torch.uint8, device=P.device)
+        st = L.mp_dense_wgrad_relu_f32(ptr(P), P.stride(0), ptr(G), G.stride(0), ptr(Y), Y.stride(0), ptr(gm),
+                                       gm.stride(0), M, F, d, ptr(out), ptr(db), ptr(ws), nb.value, _stream())
+    if st in (2, 5):
+        return None
+    check(st, "mp_dense_wgrad_relu_f32")
+    return out, db, gm
+
+
 def _wgrad_and_bias(X, g, need_w, need_b):
     """(X^T g, sum_m g[m]) for a transform's backward pass: one kernel when both are wanted"""
     if need_w and need_b:
@@ -717,6 +739,41 @@ def _(X, G, want_w, want_b):
     return (G.new_empty((X.size(1), G.size(1)) if want_w else (0,)), G.new_empty((G.size(1),) if want_b else (0,)))
 
 
+@custom_op("mp::dense_wgrad_relu_raw", mutates_args=(), device_types="cuda")
+def _op_dense_wgrad_relu_raw(X: Tensor, G: Tensor, Y: Tensor, want_b: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """(X^T gm, column sums of gm, gm) with gm = G * [Y > 0]: the ReLU backward folded into the weight-gradient pass"""
+    Gc = G if (G.stride(-1) == 1 and G.dim() == 2) else G.contiguous()
+    Yc = Y if Y.stride(-1) == 1 else Y.contiguous()
+    Xc = X if X.stride(-1) == 1 else X.contiguous()
+    r = _raw_dense_wgrad_relu(Xc, Gc, Yc, want_bias=want_b)
+    if r is None:     # shape outside the kernel: separate passes
+        gm = torch.ops.aten.threshold_backward(Gc, Yc, 0.0)
+        dW, db = _wgrad_and_bias(Xc, gm, True, want_b)
+        return dW, (db if db is not None else _empty_like_none(G)), gm
+    dW, db, gm = r
+    return dW, (db if db is not None else _empty_like_none(G)), gm
+
+
+@_op_dense_wgrad_relu_raw.register_fake
+def _(X, G, Y, want_b):
+    return (G.new_empty((X.size(1), G.size(1))), G.new_empty((G.size(1),) if want_b else (0,)), G.new_empty(G.shape))
+
+
+def _masked_grads(P, gout, out, relu, need_w, need_b):
+    """(gm, dW, db) for a transform with an optional ReLU epilogue: with ReLU and a weight gradient wanted the mask rides
+    in the weight-gradient pass (one kernel); otherwise threshold_backward / plain weight gradient"""
+    if relu and need_w and P is not None and P.numel() > 0:
+        dW, db, gm = torch.ops.mp.dense_wgrad_relu_raw(P, gout, out, need_b)
+        return gm, dW, _none_if_empty(db)
+    gm = gout.contiguous()
+    if relu:
+        gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
+    if need_w or need_b:
+        dW, db = torch.ops.mp.dense_wgrad_raw(P, gm, need_w, need_b)
+        return gm, _none_if_empty(dW), _none_if_empty(db)
+    return gm, None, None
+
+
 # ---- differentiable operators ---------------------------------------------------------------
 @custom_op("mp::spmm", mutates_args=(), device_types="cuda")
 def _op_spmm(x: Tensor, graph: int, reduce: int, self_scale: float, bias: Optional[Tensor],
@@ -826,17 +883,14 @@ def _dense_setup(ctx, inputs, output):
 
 def _dense_backward(ctx, g):
     P, W, Q, W_id, out = ctx.saved_tensors
-    if ctx.relu:
-        g = torch.ops.aten.threshold_backward(g, out, 0.0)
-    g = g.contiguous()
     need = ctx.needs_input_grad
-    # g @ W^T is a plain product -> library GEMM (9.8 vs 11.8 ms at 10^7 x 256 x 256); the weight and bias gradients
-    # come out of one pass of the engine's split-K kernel
+    # the weight and bias gradients come out of one pass of the engine's split-K kernel, which also applies the ReLU
+    # mask to g on the way; g @ W^T is a plain product -> library GEMM (9.8 vs 11.8 ms at 10^7 x 256 x 256)
+    g, dW, db = _masked_grads(P, g, out, ctx.relu, need[1], ctx.has_bias and need[4])
     dP = torch.mm(g, W.t()) if need[0] else None
-    dW, db = torch.ops.mp.dense_wgrad_raw(P, g, need[1], ctx.has_bias and need[4])
     dQ = torch.mm(g, W_id.t()) if (ctx.has_q and need[2]) else None
     dWid = torch.ops.mp.dense_wgrad_raw(Q, g, True, False)[0] if (ctx.has_q and need[3]) else None
-    return dP, _none_if_empty(dW), dQ, dWid, _none_if_empty(db), None
+    return dP, dW, dQ, dWid, db, None
 
 
 register_autograd("mp::dense_fused", _dense_backward, setup_context=_dense_setup)
@@ -871,21 +925,18 @@ def _agg_dense_setup(ctx, inputs, output):
 
 def _agg_dense_backward(ctx, gout, _gP):
     P, W, out, x = ctx.saved_tensors
-    gm = gout.contiguous()
-    if ctx.relu:
-        gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
     need = ctx.needs_input_grad
     if not ctx.want_P and (need[1]):   # the aggregated rows were not kept (called outside grad mode bookkeeping)
         P = torch.ops.mp.spmm_raw(x, ctx.graph, 0, ctx.reduce, x if ctx.self_scale != 0.0 else None, ctx.self_scale,
                                   None, False, False)[0]
-    dW, db = torch.ops.mp.dense_wgrad_raw(P, gm, need[1], ctx.has_bias and need[2]) if (need[1] or need[2]) else (None, None)
+    gm, dW, db = _masked_grads(P, gout, out, ctx.relu, need[1], ctx.has_bias and need[2])
     dx = None
     if need[0]:
         # dx = (A^T g + s g) W^T: the same one-kernel layer on the transposed operator (mean: entries w / count)
         variant = 1 if ctx.reduce == _lib.SUM else 2
         dx = torch.ops.mp.agg_dense_raw(gm, W.t().contiguous(), None, ctx.graph, variant, _lib.SUM,
                                         gm if ctx.self_scale != 0.0 else None, ctx.self_scale, False, False)[0]
-    return dx, _none_if_empty(dW), _none_if_empty(db), None, None, None, None, None
+    return dx, dW, db, None, None, None, None, None
 
 
 register_autograd("mp::agg_dense", _agg_dense_backward, setup_context=_agg_dense_setup)
@@ -925,14 +976,11 @@ def _agg_dense_id_setup(ctx, inputs, output):
 
 def _agg_dense_id_backward(ctx, gout, _gP, _gxid):
     P, W, W_id, x_id, id_index, out, x = ctx.saved_tensors
-    gm = gout.contiguous()
-    if ctx.relu:
-        gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
     need = ctx.needs_input_grad
     if not ctx.want_P and need[1]:
         P = torch.ops.mp.spmm_raw(x, ctx.graph, 0, _lib.SUM, x if ctx.self_scale != 0.0 else None, ctx.self_scale,
                                   None, False, False)[0]
-    dW, db = torch.ops.mp.dense_wgrad_raw(P, gm, need[1], ctx.has_bias and need[3]) if (need[1] or need[3]) else (None, None)
+    gm, dW, db = _masked_grads(P, gout, out, ctx.relu, need[1], ctx.has_bias and need[3])
     # identity branch: T = A_id^T g [n_id, d_out];  dW_id = x_id^T T ;  dx[id] += T W_id^T
     T = torch.ops.mp.id_branch_t_raw(gm, ctx.graph, id_index) if (need[0] or need[2]) else None
     dWid = torch.mm(x_id.t(), T) if need[2] else None
@@ -941,7 +989,7 @@ def _agg_dense_id_backward(ctx, gout, _gP, _gxid):
         dx = torch.ops.mp.agg_dense_raw(gm, W.t().contiguous(), None, ctx.graph, 1, _lib.SUM,
                                         gm if ctx.self_scale != 0.0 else None, ctx.self_scale, False, False)[0]
         dx = dx.index_add(0, id_index.to(torch.int64), torch.mm(T, W_id.t()))
-    return dx, _none_if_empty(dW), dWid, _none_if_empty(db), None, None, None, None, None
+    return dx, dW, dWid, db, None, None, None, None, None
 
 
 register_autograd("mp::agg_dense_id", _agg_dense_id_backward, setup_context=_agg_dense_id_setup)

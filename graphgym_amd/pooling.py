@@ -17,9 +17,7 @@ def pool_operator(batch, num_nodes, id=None, size=None):
     nodes = torch.arange(num_nodes, device=batch.device) if id is None else id.to(torch.int64)
     owner = batch.to(torch.int64) if id is None else batch.to(torch.int64).index_select(0, nodes)
     size = int(batch.max().item()) + 1 if size is None else int(size)
-    g = CSRGraph.from_edge_index(torch.stack([nodes, owner]), size)      # [source; destination]
-    g.num_cols = int(num_nodes)
-    return g
+    return CSRGraph.from_edge_index(torch.stack([nodes, owner]), size, num_cols=int(num_nodes))   # [source; destination]
 
 
 def _pool(x, batch, id, size, reduce, operator=None):

@@ -158,7 +158,10 @@ int mp_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val
                      void* ws, size_t ws_bytes, mp_stream_t stream);
 
 /* weighted degree: deg[i] = sum of val over row i (axis ROW) or column i (axis COL);
- * val == NULL counts entries.  (K6: sparse_adj.py:84-85, idconv.py:56,144) */
+ * val == NULL counts entries.  (K6: sparse_adj.py:84-85, idconv.py:56,144)
+ * AXIS_ROW is a fixed-order (Kahan) row sum: bitwise reproducible.  AXIS_COL on a WEIGHTED operator adds with float
+ * atomics (order-dependent in the last ulp; exact for val == NULL): for reproducible by-source degrees run AXIS_ROW on
+ * the transposed CSR (mp_csr_transpose), as graphgym_amd.graph.CSRGraph.degree('col') does. */
 int mp_csr_degree(const int32_t* rowptr, const int32_t* col, const float* val,
                   int64_t N, int64_t nnz, int axis, float* deg, mp_stream_t stream);
 
@@ -334,6 +337,31 @@ int mp_dense_wgrad_ws_bytes(int64_t M, int32_t F, int32_t d, size_t* bytes_host)
 int mp_dense_wgrad_f32(const float* P, int64_t ldp, const float* G, int64_t ldg, int64_t M,
                        int32_t F, int32_t d, float* dW, float* dbias, void* ws, size_t ws_bytes,
                        mp_stream_t stream);
+
+/* The same pass with the backward of a ReLU epilogue folded in: G is masked by [Y > 0] (Y = the forward output of the
+ * transform whose gradient this is) as it is read, dW = P^T (G * [Y > 0]), dbias its column sums, and GM (optional,
+ * [M, d], may alias G) receives the masked gradient for the input-gradient launch that follows — the separate
+ * elementwise masking pass of loss.backward() (graphgym/train.py:24) disappears. */
+int mp_dense_wgrad_relu_f32(const float* P, int64_t ldp, const float* G, int64_t ldg, const float* Y, int64_t ldy,
+                            float* GM, int64_t ldgm, int64_t M, int32_t F, int32_t d, float* dW, float* dbias,
+                            void* ws, size_t ws_bytes, mp_stream_t stream);
+
+/* ------------------------------------------------------------------ *
+ * Loss of the training step that drives the path: softmax cross-entropy  *
+ * over the labelled rows (graphgym/loss.py:53-68 masked_logits =          *
+ * logits[node_label_index], mean softmax-CE; loss.py:20-37 torch path).   *
+ * index [n_sel] int64 selects rows of logits (NULL = rows 0..n_sel-1);   *
+ * labels [n_sel] int64 in [0, C).                                         *
+ *   rows:  row_loss[k] = logsumexp(z_i) - z_i[y_k]                        *
+ *   bwd:   dlogits[i, :] = (softmax(z_i) - onehot(y_k)) * gscale[0] * inv_n *
+ *          (gscale: device scalar, the upstream gradient; rows not in     *
+ *          index are left untouched — zero dlogits first for a subset)    *
+ * ------------------------------------------------------------------ */
+int mp_softmax_ce_rows_f32(const float* logits, int64_t ld, const int64_t* labels, const int64_t* index,
+                           int64_t n_sel, int32_t C, float* row_loss, mp_stream_t stream);
+int mp_softmax_ce_bwd_f32(const float* logits, int64_t ld, const int64_t* labels, const int64_t* index,
+                          int64_t n_sel, int32_t C, const float* gscale, float inv_n, float* dlogits, int64_t ldd,
+                          mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * Identity-row update (K10): H[id[k], :] += U[k, :]                   *

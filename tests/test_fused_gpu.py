@@ -17,6 +17,19 @@ def close(a, ref, tol=1e-5):
     assert err <= tol * scale, f"max err {err:.3e} > {tol:.0e} * {scale:.3g}"
 
 
+def relu_like_engine(pre, out_engine):
+    """A ReLU input within fp32 rounding of zero has an arbitrary subgradient (and with ~10^5 activations per case a few
+    ARE that close): differentiate the float64 reference through the engine's own pattern (output > 0), after checking
+    that the pattern differs from the reference's sign test only where the input is ~0."""
+    mask = (out_engine.detach().cpu() > 0)
+    own = pre.detach() > 0
+    off = own != mask
+    if bool(off.any()):
+        worst = float(pre.detach().abs()[off].max())
+        assert worst <= 1e-5 * float(pre.detach().abs().max()), f"activation pattern differs at |input| = {worst:.3e}"
+    return pre * mask.to(pre.dtype)
+
+
 def make_graph(n, E, seed, hubs=False, weighted=True):
     g = torch.Generator().manual_seed(seed)
     ei = torch.randint(0, n, (2, E), generator=g)
@@ -52,19 +65,19 @@ def test_agg_dense_matches_oracle(dev, n, E, F, d, weighted, hubs, self_scale):
     G = ga.CSRGraph.from_edge_index(ei.to(dev), n, None if w is None else w.to(dev), dst_row=0)
     assert ops.agg_dense_supported(G, x.to(dev), W.to(dev))
     for relu in (False, True):
-        xr, Wr, br = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
-        # float64 oracle: the bar is 1e-5 on the result, and fp32 CPU sums of 7000-entry rows are themselves off
-        agg = torch.zeros(n, F, dtype=torch.float64).index_add_(
-            0, ei[0], xr.double()[ei[1]] * (w.double().unsqueeze(1) if w is not None else 1.0))
-        ref = (agg + self_scale * xr.double()) @ Wr.double() + br.double()
-        ref = torch.relu(ref) if relu else ref
         up = torch.randn(n, d, generator=gen)
-        ref.backward(up.double())
         xd = x.to(dev).requires_grad_(True)
         Wd = W.to(dev).requires_grad_(True)
         bd = b.to(dev).requires_grad_(True)
         out = ops.agg_dense(G, xd, Wd, bias=bd, relu=relu, self_scale=self_scale)
         out.backward(up.to(dev))
+        xr, Wr, br = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        # float64 oracle: the bar is 1e-5 on the result, and fp32 CPU sums of 7000-entry rows are themselves off
+        agg = torch.zeros(n, F, dtype=torch.float64).index_add_(
+            0, ei[0], xr.double()[ei[1]] * (w.double().unsqueeze(1) if w is not None else 1.0))
+        ref = (agg + self_scale * xr.double()) @ Wr.double() + br.double()
+        ref = relu_like_engine(ref, out) if relu else ref
+        ref.backward(up.double())
         close(out, ref)
         close(xd.grad, xr.grad)
         close(Wd.grad, Wr.grad, 2e-5)
@@ -286,19 +299,19 @@ def test_agg_dense_id_matches_oracle(dev, n, E, F, d, weighted, hubs, n_id, self
         ids[0] = 5                                                  # a hub row's own node among the identity nodes
     G = ga.CSRGraph.from_edge_index(ei.to(dev), n, None if w is None else w.to(dev), dst_row=0)
     for relu in (False, True):
+        up = torch.randn(n, d, generator=gen)
+        xd, Wd, Wid_d, bd = (t.to(dev).requires_grad_(True) for t in (x, W, Wid, b))
+        out = ops.agg_dense_id(G, xd, Wd, Wid_d, ids.to(dev), bias=bd, relu=relu, self_scale=self_scale)
+        assert out is not None
+        out.backward(up.to(dev))
         xr, Wr, Wir, br = (t.clone().double().requires_grad_(True) for t in (x, W, Wid, b))
         h = xr @ Wr
         h = h.index_add(0, ids, xr[ids] @ Wir)                     # TfgIDLayer.py:513-515
         agg = torch.zeros(n, d, dtype=torch.float64).index_add_(
             0, ei[0], h[ei[1]] * (w.double().unsqueeze(1) if w is not None else 1.0))
         ref = agg + self_scale * (xr @ Wr) + br
-        ref = torch.relu(ref) if relu else ref
-        up = torch.randn(n, d, generator=gen)
+        ref = relu_like_engine(ref, out) if relu else ref
         ref.backward(up.double())
-        xd, Wd, Wid_d, bd = (t.to(dev).requires_grad_(True) for t in (x, W, Wid, b))
-        out = ops.agg_dense_id(G, xd, Wd, Wid_d, ids.to(dev), bias=bd, relu=relu, self_scale=self_scale)
-        assert out is not None
-        out.backward(up.to(dev))
         close(out, ref)
         close(xd.grad, xr.grad)
         close(Wd.grad, Wr.grad, 2e-5)

@@ -567,3 +567,23 @@ def test_c_abi_error_codes_on_device(dev):
     P = torch.randn(10, 12, device=dev); W = torch.randn(12, 8, device=dev); out = torch.empty(10, 8, device=dev)
     assert L.mp_dense_fused_f32(ptr(P), 12, ptr(W), ptr(P), 12, None, None, 0, ptr(out), 8, 10, 12, 8, _stream()) == 1
     assert L.mp_dense_fused_f32(ptr(P), 11, ptr(W), None, 0, None, None, 0, ptr(out), 8, 10, 12, 8, _stream()) == 1
+
+
+def test_by_source_normalisation_is_bitwise_reproducible(dev):
+    """gcn_norm('col') (GCNIDConvLayer.norm, idconv.py:132-148: degrees scattered by SOURCE) sums in a fixed order over
+    the transposed CSR: two builds are bit-identical, and match the oracle"""
+    import graphgym_amd as ga
+    g = torch.Generator().manual_seed(77)
+    N, E = 3000, 60000
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[0, :5000] = 3                                               # a source with thousands of out-edges
+    w = torch.rand(E, generator=g) + 0.01
+    builds = []
+    for _ in range(2):
+        G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev), remove_self_loops=True, add_self_loops=True,
+                                        keep_loop_weight=True).gcn_norm("col")
+        builds.append(G.val.clone())
+    assert torch.equal(builds[0], builds[1])
+    ei_r, norm_r = R.pyg_gcn_norm(ei, N, w)
+    ref = torch.zeros(N, N, dtype=torch.float64).index_put_((ei_r[1], ei_r[0]), norm_r.double(), accumulate=True)
+    close(_dense(G), ref, 1e-5)

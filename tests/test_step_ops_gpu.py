@@ -1,0 +1,90 @@
+"""Operators around the aggregation inside a training step: the weight-gradient pass with the ReLU backward folded in
+(mp_dense_wgrad_relu_f32) and the softmax cross-entropy over labelled rows (mp_softmax_ce_*; graphgym/loss.py:53-68),
+against float64 torch."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _tol import assert_close_all
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,Fi,d", [(1000, 256, 256), (777, 264, 132), (500, 1433, 128), (333, 1, 7), (70000, 128, 64),
+                                    (129, 8, 260)])
+def test_wgrad_with_relu_mask(dev, M, Fi, d):
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(M + d)
+    P = torch.randn(M, Fi, generator=g)
+    G = torch.randn(M, d, generator=g)
+    Y = torch.relu(torch.randn(M, d, generator=g))                  # a ReLU output: exact zeros where it was clipped
+    r = ops._raw_dense_wgrad_relu(P.to(dev), G.to(dev), Y.to(dev), want_bias=True)
+    assert r is not None
+    dW, db, gm = r
+    ref_gm = torch.where(Y > 0, G, torch.zeros_like(G))
+    assert torch.equal(gm.cpu(), ref_gm)                            # the masked gradient is exact
+    assert_close_all(dW, P.double().t() @ ref_gm.double(), 1e-5, ref32=P.t() @ ref_gm, what="dW")
+    assert_close_all(db, ref_gm.double().sum(0), 1e-5, ref32=ref_gm.sum(0), what="db")
+    # aliasing the output with the input gradient is allowed (masking is idempotent)
+    G2 = G.to(dev).clone()
+    import ctypes as C
+    from graphgym_amd._lib import lib, ptr, check
+    from graphgym_amd.graph import _stream
+    L = lib()
+    nb = C.c_size_t(0)
+    check(L.mp_dense_wgrad_ws_bytes(M, Fi, d, C.byref(nb)))
+    ws = torch.empty(max(nb.value, 1), dtype=torch.uint8, device=dev)
+    dW2 = torch.empty(Fi, d, device=dev)
+    Pd, Yd = P.to(dev), Y.to(dev)
+    check(L.mp_dense_wgrad_relu_f32(ptr(Pd), Fi, ptr(G2), d, ptr(Yd), d, ptr(G2), d, M, Fi, d, ptr(dW2), None, ptr(ws),
+                                    nb.value, _stream()))
+    assert torch.equal(G2.cpu(), ref_gm) and torch.equal(dW2, dW)
+
+
+def test_relu_layers_backward_has_no_separate_mask_pass(dev):
+    """the backward of a transform with a ReLU epilogue dispatches mp::dense_wgrad_relu_raw and no aten threshold op"""
+    from graphgym_amd import ops
+    from torch.utils._python_dispatch import TorchDispatchMode
+    seen = []
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5000, 64, generator=g).to(dev).requires_grad_(True)
+    W = torch.randn(64, 64, generator=g).to(dev).requires_grad_(True)
+    b = torch.randn(64, generator=g).to(dev).requires_grad_(True)
+    out = ops.dense_fused(x, W, bias=b, relu=True)
+    with Spy():
+        out.sum().backward()
+    assert any("dense_wgrad_relu_raw" in s for s in seen), seen
+    assert not any("threshold_backward" in s for s in seen), seen
+    xr, Wr, br = (t.detach().cpu().double().requires_grad_(True) for t in (x, W, b))
+    torch.relu(xr @ Wr + br).sum().backward()
+    assert_close_all(W.grad, Wr.grad, 1e-5, what="dW")
+    assert_close_all(x.grad, xr.grad, 1e-5, what="dx")
+    assert_close_all(b.grad, br.grad, 1e-5, what="db")
+
+
+@pytest.mark.parametrize("subset", [False, True])
+def test_softmax_cross_entropy_matches_torch(dev, subset):
+    from graphgym_amd import nn as mpnn
+    g = torch.Generator().manual_seed(3)
+    N, Cn = 400_000, 7
+    z = (torch.randn(N, Cn, generator=g) * 3).requires_grad_(True)
+    idx = torch.randperm(N, generator=g)[: N // 3] if subset else None
+    y = torch.randint(0, Cn, (N // 3 if subset else N,), generator=g)
+    zd = z.detach().to(dev).requires_grad_(True)
+    loss = mpnn.softmax_cross_entropy(zd, y.to(dev), None if idx is None else idx.to(dev))
+    (loss * 1.7).backward()
+    z64 = z.detach().double().requires_grad_(True)
+    ref = F.cross_entropy(z64 if idx is None else z64[idx], y, reduction="mean")
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    assert float((zd.grad.cpu().double() - z64.grad).abs().max()) <= 1e-6 * float(z64.grad.abs().max())
+    # the harness' loss (graphgym/loss.py:53-68) goes through it
+    from graphgym_amd import harness as H
+    lab_idx = torch.arange(N, device=dev) if idx is None else idx.to(dev)
+    l2 = H.tfg_loss(zd.detach(), lab_idx, y.to(dev), [])
+    assert abs(float(l2) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))

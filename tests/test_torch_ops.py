@@ -6,7 +6,8 @@ import torch
 
 NAMES = ["spmm", "idgnn_agg", "agg_dense", "agg_dense_id", "dense_fused", "bn_act",
          "spmm_raw", "spmm_rows_raw", "spmm_max_bwd_raw", "idgnn_agg_raw", "agg_dense_raw", "agg_dense_id_raw",
-         "id_branch_t_raw", "dense_fused_raw", "dense_wgrad_raw", "bn_fwd_raw", "bn_bwd_raw"]
+         "id_branch_t_raw", "dense_fused_raw", "dense_wgrad_raw", "dense_wgrad_relu_raw", "bn_fwd_raw", "bn_bwd_raw",
+         "softmax_ce", "softmax_ce_rows_raw", "softmax_ce_bwd_raw"]
 
 
 def test_ops_are_registered_with_schemas():
@@ -74,6 +75,10 @@ def test_opcheck(dev):
         (torch.ops.mp.bn_act.default, (t(n, F), t(F), t(F), 1e-5, True)),
         (torch.ops.mp.spmm_raw.default, (t(n, F, grad=False), h, 1, 0, None, 0.0, None, False, False)),
         (torch.ops.mp.dense_wgrad_raw.default, (t(n, F, grad=False), t(n, d, grad=False), True, True)),
+        (torch.ops.mp.dense_wgrad_relu_raw.default, (t(n, F, grad=False), t(n, d, grad=False),
+                                                     torch.relu(t(n, d, grad=False)), True)),
+        (torch.ops.mp.softmax_ce.default, (t(n, 7), torch.randint(0, 7, (n // 2,), generator=gen).to(dev),
+                                           torch.randperm(n, generator=gen)[: n // 2].to(dev))),
     ]
     for op, args in cases:
         res = torch.library.opcheck(op, args, raise_exception=True)
