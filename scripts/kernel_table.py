@@ -4,7 +4,7 @@ import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import graphgym_amd as ga
-from graphgym_amd import graphgen, ops, nn as mpnn
+from graphgym_amd import graphgen, ops, nn as mpnn, placement
 from graphgym_amd.graph import CSRGraph
 dev = torch.device("cuda:0")
 n, d = int(os.environ.get("NODES", "10000000")), 256
@@ -57,8 +57,9 @@ def pl():
 rec("plan build (segments + hubs; once per graph)", timeit(pl, iters=3, warm=1), note="cached with the pattern (first build: ~50 us of kernels + one host read)")
 del g0
 
-x = torch.rand(n, d, device=dev) * 2 - 1
-y = torch.empty(n, d, device=dev)
+x = placement.empty_or_torch((n, d), dev)            # operands through the engine's placement, as the operators allocate
+x.uniform_(-1, 1)
+y = placement.empty_or_torch((n, d), dev, reads=(x,))
 agg_bytes = (nnz * (d * 4 + 8) + n * (d * 4 + 4)) / 1e9
 for red, name in ((0, "sum"), (1, "mean"), (2, "max")):
     t = timeit(lambda: ops._raw_spmm(g, x, red, out=y, want_argmax=False))
@@ -68,13 +69,9 @@ rec("agg_rows sum on the transposed operator (backward)", t, agg_bytes)
 t = timeit(lambda: ops._raw_spmm(g, x, 0, S=x, self_scale=1.0, out=y))
 rec("agg_rows sum + self term (GIN combine)", t, agg_bytes + n * d * 4 / 1e9)
 ids = torch.arange(0, n, 100, device=dev)
-col_m = g.mark_ids(ids)
-q = torch.empty(n, d, device=dev)
-def two_branch():
-    ops.idgnn_aggregate(g, ids, x, col_marked=col_m)
-t = timeit(two_branch)
-rec("agg_rows two-branch (P and Q in one pass, 1 % identity nodes)", t, agg_bytes + n * d * 4 / 1e9)
-del q
+with torch.no_grad():
+    t_two = timeit(lambda: ops.idgnn_aggregate(g, ids, x))
+rec("agg_rows two-branch (P and Q in one pass, 1 % identity nodes)", t_two, agg_bytes + n * d * 4 / 1e9)
 # attention pieces
 s = None
 t = timeit(lambda: ops._raw_sddmm_dot(g, x, x, 1, 1.0))
@@ -92,6 +89,39 @@ t = timeit(lambda: ops._raw_dense_wgrad(x, y, want_bias=True))
 rec("dense_wgrad (+ bias gradient)", t, tflop=2.0 * n * d * d / 1e12)
 t = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True, out=y))
 rec("agg_dense (aggregate -> transform, one kernel)", t, agg_bytes, tflop=2.0 * n * d * d / 1e12, note="moves the aggregation's bytes AND does the transform's flops")
+# the ID layer: act(A (x W + S x W_id) + b), 1 % identity nodes
+Wid = torch.randn(d, d, device=dev) * 0.05
+with torch.no_grad():
+    t_id = timeit(lambda: ops.agg_dense_id(g, x, W, Wid, ids, bias=b, relu=True))
+    def id_two_kernels():
+        P, Q = ops.idgnn_aggregate(g, ids, x)
+        return ops.dense_fused(P, W, Q, Wid, b, relu=True)
+    t_id2 = timeit(id_two_kernels)
+rec("ID-GCN layer, one-kernel form (agg_dense + identity fix-up)", t_id, agg_bytes, tflop=2.0 * n * d * d / 1e12,
+    note="round 1's form below: two-branch aggregation + dual GEMM")
+rec("ID-GCN layer, round-1 form (two-branch aggregation, then P W + Q W_id)", t_id2, agg_bytes + 3 * n * d * 4 / 1e9, tflop=4.0 * n * d * d / 1e12)
+# weight gradient with the ReLU backward folded in vs mask pass + weight gradient
+yr = torch.relu(y)
+def mask_then_wgrad():
+    gm = torch.ops.aten.threshold_backward(x, yr, 0.0)
+    return ops._raw_dense_wgrad(x, gm, want_bias=True)
+t = timeit(lambda: ops._raw_dense_wgrad_relu(x, x, yr, want_bias=True))
+rec("dense_wgrad with the ReLU mask folded in (+ masked gradient out)", t, tflop=2.0 * n * d * d / 1e12)
+t = timeit(mask_then_wgrad)
+rec("threshold_backward pass + dense_wgrad (round 1's backward)", t, tflop=2.0 * n * d * d / 1e12)
+del yr
+# softmax cross-entropy over 10^7 labelled rows, 7 classes
+z = torch.randn(n, 7, device=dev).requires_grad_(True)
+lab = torch.randint(0, 7, (n,), device=dev)
+def ce_engine():
+    z.grad = None
+    mpnn.softmax_cross_entropy(z, lab).backward()
+def ce_torch():
+    z.grad = None
+    torch.nn.functional.cross_entropy(z, lab).backward()
+rec("softmax cross-entropy fwd + bwd, engine", timeit(ce_engine), 4 * n * 7 * 4 / 1e9)
+rec("softmax cross-entropy fwd + bwd, torch", timeit(ce_torch), 4 * n * 7 * 4 / 1e9)
+del z, lab
 # batch norm
 bn = mpnn.BatchNorm1d(d, relu=True).to(dev)
 xr = x.clone().requires_grad_(True)

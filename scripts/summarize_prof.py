@@ -41,12 +41,16 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv")):
     probe_at = next((int(r["Start_Timestamp"]) for r in recs if "read_probe_kernel" in r["Kernel_Name"]), None)
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in recs
          if "agg_rows_kernel" in r["Kernel_Name"] and (probe_at is None or int(r["Start_Timestamp"]) < probe_at)]
+    # bench.py runs `warmup` + `steps` launches back to back, then up to 10 cold launches (a memset in between):
+    # with --steps 10 --warmup 3 the timed region is launches 3..12 of the trace
+    if len(d) >= 13:
+        d = d[:13]
     if len(d) >= 10:
         timed = {"launches_in_trace_before_the_probes": len(d), "last_10_launches_avg_ns": sum(d[-10:]) / 10,
                  "min_ns": min(d),
-                 "note": "the last 10 launches before the bandwidth probes are bench.py's timed region (--steps 10); earlier "
-                         "ones are the three candidate output buffers (one or two of them in the slow placement band) and "
-                         "warm-up; the launches after the probes belong to the `layer` side measurement"}
+                 "note": "the last 10 launches before the flush memsets / bandwidth probes are bench.py's timed region "
+                         "(--steps 10); earlier ones are warm-up; later ones are the cold launches, the backward and the "
+                         "`layer` side measurements"}
 pmc = {}
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for f in glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv")):

@@ -111,4 +111,4 @@ def test_layers_run_on_the_registered_ops(dev):
     with Spy():
         layer([x, ei, ids]).sum().backward()
     assert "agg_dense_id" in seen or "agg_dense_id_raw" in seen, seen
-    assert "dense_wgrad_raw" in seen and "agg_dense_raw" in seen, seen       # the backward formula is registered ops too
+    assert ({"dense_wgrad_raw", "dense_wgrad_relu_raw"} & seen) and "agg_dense_raw" in seen, seen   # the backward formula is registered ops too
