@@ -79,9 +79,11 @@ PROTOTYPES = {
     "mp_sddmm_dot_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _i32, _f32, _p, _p]),
     "mp_sddmm_dot_stream_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _f32, _p, _p]),
     "mp_sddmm_add_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _f32, _p, _p]),
+    "mp_gat_alpha_f32": (C.c_int, [_p, _p, _i64, _i64, _i32, _p, _p, _f32, _p, _p]),
     "mp_csr_row_softmax_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
     "mp_csr_row_softmax_bwd_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     "mp_sddmm_grad_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _p]),
+    "mp_spmm_csr_heads_f32": (C.c_int, [_p, _p, _p, _i64, _p, _pi32, _i32, _p, _i64, _p, _i64, _i32, _p, _sz, _p]),
     "mp_spmm_heads_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _p]),
     "mp_ego_ws_bytes": (C.c_int, [_i64, _i64, _psz]),
     "mp_ego_expand_count": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _sz, _p, _p]),

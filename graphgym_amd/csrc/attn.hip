@@ -178,6 +178,50 @@ __global__ __launch_bounds__(kBlock) void row_softmax_kernel(const int32_t* __re
   }
 }
 
+// Additive attention coefficients in one pass, all heads: alpha[e, h] = softmax over row r of
+// leaky_relu(a_dst[r, h] + a_src[col[e], h])  (idconv.py:319-327; torch_geometric GATConv [3P]).  The scores are never
+// stored: the three sweeps of the row softmax (max, sum, write) recompute them from the two per-node terms, which sit
+// in L2.  Replaces one sddmm_add launch per head + a concatenation + the row softmax of round 1.
+__global__ __launch_bounds__(kBlock) void gat_alpha_kernel(const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col, int64_t N, int32_t heads,
+                                                           const float* __restrict__ a_dst,
+                                                           const float* __restrict__ a_src, float slope, float* out) {
+  const int sub = threadIdx.x % kSmLanes;
+  const int64_t groups = (int64_t)gridDim.x * (kBlock / kSmLanes);
+  const int64_t rounds = (N + groups - 1) / groups;     // the same for every lane: shuffles need the wave converged
+  for (int64_t it = 0; it < rounds; ++it) {
+    const int64_t r0 = it * groups + (int64_t)blockIdx.x * (kBlock / kSmLanes) + threadIdx.x / kSmLanes;
+    const bool live = r0 < N;
+    const int64_t r = live ? r0 : N - 1;
+    const int e0 = live ? rowptr[r] : 0, e1 = live ? rowptr[r + 1] : 0;
+    int trips = (e1 - e0 + kSmLanes - 1) / kSmLanes;
+    for (int off = kSmLanes; off < kWave; off <<= 1) trips = max(trips, __shfl_xor(trips, off, kWave));
+    for (int h = 0; h < heads; ++h) {
+      const float ad = a_dst[r * heads + h];
+      auto score = [&](int e) {
+        const float v = ad + a_src[(int64_t)col[e] * heads + h];
+        return v > 0.f ? v : slope * v;
+      };
+      float m = -INFINITY;
+      for (int t = 0; t < trips; ++t) {
+        const int e = e0 + t * kSmLanes + sub;
+        if (e < e1) m = fmaxf(m, score(e));
+      }
+      for (int off = kSmLanes >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+      float z = 0.f;
+      for (int t = 0; t < trips; ++t) {
+        const int e = e0 + t * kSmLanes + sub;
+        if (e < e1) z += expf(score(e) - m);
+      }
+      z = wave_sum_seg(z, kSmLanes);
+      for (int t = 0; t < trips; ++t) {
+        const int e = e0 + t * kSmLanes + sub;
+        if (e < e1) out[(int64_t)e * heads + h] = expf(score(e) - m) / z;
+      }
+    }
+  }
+}
+
 // ds = p * (dp - sum_row(p * dp))
 __global__ __launch_bounds__(kBlock) void row_softmax_bwd_kernel(const int32_t* __restrict__ rowptr,
                                                                  int64_t N, int32_t heads,
@@ -314,6 +358,17 @@ int mp_csr_row_softmax_f32(const int32_t* rowptr, int64_t N, int32_t heads, cons
   if (!s || !out) return MP_ERR_INVALID_ARG;
   hipLaunchKernelGGL(row_softmax_kernel, dim3(flat_grid(N * kSmLanes)), dim3(kBlock), 0, as_stream(stream), rowptr, N,
                      heads, s, out);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+int mp_gat_alpha_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t nnz, int32_t heads,
+                     const float* a_dst, const float* a_src, float slope, float* alpha, mp_stream_t stream) {
+  if (!rowptr || N < 0 || nnz < 0 || heads < 1 || (nnz > 0 && (!col || !a_dst || !a_src || !alpha)))
+    return MP_ERR_INVALID_ARG;
+  if (N == 0 || nnz == 0) return MP_OK;
+  hipLaunchKernelGGL(gat_alpha_kernel, dim3(flat_grid(N * kSmLanes)), dim3(kBlock), 0, as_stream(stream), rowptr, col,
+                     N, heads, a_dst, a_src, slope, alpha);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

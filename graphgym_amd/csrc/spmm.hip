@@ -41,6 +41,7 @@ struct AggArgs {
   float l2_eps;
   int32_t* argmax;
   int32_t d;
+  int32_t head_width;       // NH > 1: val is [nnz, NH] and head h owns columns [h * head_width, (h + 1) * head_width)
   // hub path
   const int32_t* header;
   const int32_t* hub_row;
@@ -149,7 +150,9 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int row, int deg,
 // Main kernel: one wave per segment of whole rows.  Kept from the round-1 variant study: U = 8 rows
 // in flight, non-temporal stores of Y (-1.2 %); non-temporal index loads, index prefetch and an LDS-staged index
 // tile measured within 0.3 % and are not built.
-template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2, int U>
+// NH > 1 (multi-head attention, TfgIDLayer.py:333-355): every entry carries NH weights (val [nnz, NH]); a lane applies
+// the weight of the head its columns belong to, so all heads aggregate in one launch on full 1 KiB row loads.
+template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2, int U, int NH = 1>
 __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
   if (r0 >= r1) return;
 
   const float* __restrict__ xlane = a.X + c0ld;
+  const int myh = NH > 1 ? c0ld / a.head_width : 0;
 
   // row ends of up to 64 rows live in one VGPR; the current one is broadcast to an SGPR
   int rbase = r0;
@@ -196,8 +200,9 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
   for (int ec = e0; ec < e1; ec += kWave) {
     const int me = min(ec + lane, e1 - 1);
     const int cv = a.col[me];
-    float wv = 1.f;
-    if (WEIGHTED) wv = a.val[me];
+    float wv[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) wv[h] = WEIGHTED ? a.val[(int64_t)me * NH + h] : 1.f;
     const int n = min(kWave, e1 - ec);
     for (int jb = 0; jb < n; jb += U) {
       float v[U][W];
@@ -216,7 +221,12 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
             finish_row<W, REDUCE, BRANCH2, true>(a, r, rend - rstart, acc, c0, c0ld, lane_on);
             advance();
           }
-          const float w = WEIGHTED ? bcast_f(wv, jb + j) : 1.f;
+          float w = WEIGHTED ? bcast_f(wv[0], jb + j) : 1.f;
+#pragma unroll
+          for (int h = 1; h < NH; ++h) {
+            const float wh = bcast_f(wv[h], jb + j);
+            w = myh == h ? wh : w;
+          }
           acc.add(v[j], w, BRANCH2 && cj[j] < 0, e);
         }
       }
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void agg_rows_kernel(AggArgs a) {
 }
 
 // Hub path 1/2: one wave reduces one piece (<= piece_edges entries) of a hub row.
-template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2, int U>
+template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2, int U, int NH = 1>
 __global__ __launch_bounds__(kBlock) void agg_hub_pieces_kernel(AggArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -237,6 +247,7 @@ __global__ __launch_bounds__(kBlock) void agg_hub_pieces_kernel(AggArgs a) {
   const bool lane_on = c0 < a.d;
   const int c0ld = lane_on ? c0 : 0;
   const float* __restrict__ xlane = a.X + c0ld;
+  const int myh = NH > 1 ? c0ld / a.head_width : 0;
   const int n_piece = a.header[PW_NPIECE];
 
   for (int p = blockIdx.x * kWavesPerBlock + wave; p < n_piece; p += gridDim.x * kWavesPerBlock) {
@@ -253,8 +264,9 @@ __global__ __launch_bounds__(kBlock) void agg_hub_pieces_kernel(AggArgs a) {
     for (int ec = e0; ec < e1; ec += kWave) {
       const int me = min(ec + lane, e1 - 1);
       const int cv = a.col[me];
-      float wv = 1.f;
-      if (WEIGHTED) wv = a.val[me];
+      float wv[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) wv[h] = WEIGHTED ? a.val[(int64_t)me * NH + h] : 1.f;
       const int n = min(kWave, e1 - ec);
       for (int jb = 0; jb < n; jb += U) {
         float v[U][W];
@@ -269,7 +281,12 @@ __global__ __launch_bounds__(kBlock) void agg_hub_pieces_kernel(AggArgs a) {
         for (int j = 0; j < U; ++j) {
           const int e = ec + jb + j;
           if (e < e1) {
-            const float w = WEIGHTED ? bcast_f(wv, jb + j) : 1.f;
+            float w = WEIGHTED ? bcast_f(wv[0], jb + j) : 1.f;
+#pragma unroll
+            for (int h = 1; h < NH; ++h) {
+              const float wh = bcast_f(wv[h], jb + j);
+              w = myh == h ? wh : w;
+            }
             acc.add(v[j], w, BRANCH2 && cj[j] < 0, e);
           }
         }
@@ -427,18 +444,18 @@ __global__ __launch_bounds__(kBlock) void plan_hub_kernel(const int32_t* __restr
 
 // ---- dispatch -------------------------------------------------------------
 
-template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2>
+template <int W, int REDUCE, bool WEIGHTED, bool BRANCH2, int NH = 1>
 static int launch_agg(const AggArgs& a, int64_t N, const int32_t* counts, hipStream_t st) {
   constexpr int U = 8;
   const int tiles = (int)ceil_div(a.d, kWave * W);
   dim3 grid((unsigned)ceil_div(a.n_seg, kWavesPerBlock), (unsigned)tiles);
-  hipLaunchKernelGGL((agg_rows_kernel<W, REDUCE, WEIGHTED, BRANCH2, U>), grid, dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((agg_rows_kernel<W, REDUCE, WEIGHTED, BRANCH2, U, NH>), grid, dim3(kBlock), 0, st, a);
   MP_LAUNCH_CHECK();
   const int n_hub = counts[1], n_piece = counts[2];
   if (n_hub > 0) {
     int pb = (int)ceil_div(n_piece, kWavesPerBlock);
     if (pb > kNumCU * 8) pb = kNumCU * 8;
-    hipLaunchKernelGGL((agg_hub_pieces_kernel<W, REDUCE, WEIGHTED, BRANCH2, U>), dim3(pb, tiles),
+    hipLaunchKernelGGL((agg_hub_pieces_kernel<W, REDUCE, WEIGHTED, BRANCH2, U, NH>), dim3(pb, tiles),
                        dim3(kBlock), 0, st, a);
     MP_LAUNCH_CHECK();
     int hb = (int)ceil_div(n_hub, kWavesPerBlock);
@@ -480,6 +497,7 @@ static int pick_width(const AggArgs& a) {
   auto ok = [&](int w) {
     const size_t bytes = 4u * w;
     if (a.d % w) return false;
+    if (a.head_width > 0 && a.head_width % w) return false;   // a lane's columns stay inside one head
     if (a.ldx % w || a.ldy % w) return false;
     if (a.Q && a.ldq % w) return false;
     if (a.S && a.lds % w) return false;
@@ -499,7 +517,7 @@ static int agg_common(const int32_t* rowptr, const int32_t* col, const float* va
                       float* Y, int64_t ldy, float* Q, int64_t ldq, int32_t d, int reduce,
                       const float* S, int64_t lds, float self_scale, const float* bias, int act,
                       int32_t* argmax, void* ws, size_t ws_bytes, hipStream_t st,
-                      const float* col_scale = nullptr, int l2norm = 0, float l2_eps = 1e-12f) {
+                      const float* col_scale = nullptr, int l2norm = 0, float l2_eps = 1e-12f, int heads = 1) {
   if (!rowptr || !plan || !counts || !X || !Y) return MP_ERR_INVALID_ARG;
   if (N < 0 || d <= 0 || ldx < d || ldy < d) return MP_ERR_INVALID_ARG;
   if (reduce < MP_SUM || reduce > MP_MAX) return MP_ERR_INVALID_ARG;
@@ -527,6 +545,7 @@ static int agg_common(const int32_t* rowptr, const int32_t* col, const float* va
   a.S = S; a.lds = lds; a.self_scale = self_scale; a.bias = bias; a.act = act;
   a.col_scale = col_scale; a.l2norm = l2norm; a.l2_eps = l2_eps;
   a.argmax = argmax; a.d = d;
+  a.head_width = heads > 1 ? d / heads : 0;
   a.hub_row = a.hub_base = a.hub_np = a.piece_hub = a.piece_k = nullptr;
   a.part = a.part2 = nullptr; a.part_arg = nullptr;
   if (n_piece > 0) {
@@ -546,6 +565,18 @@ static int agg_common(const int32_t* rowptr, const int32_t* col, const float* va
 
   const int w = pick_width(a);
   if (l2norm && d > kWave * w) return MP_ERR_UNSUPPORTED;   // the row must sit in one wave
+  if (heads > 1) {
+    if (!val || Q || reduce != MP_SUM || d % heads) return MP_ERR_INVALID_ARG;
+#define MP_HEADS(WV)                                                                           \
+    switch (heads) {                                                                           \
+      case 2: return launch_agg<WV, MP_SUM, true, false, 2>(a, N, counts, st);                \
+      case 4: return launch_agg<WV, MP_SUM, true, false, 4>(a, N, counts, st);                \
+      case 8: return launch_agg<WV, MP_SUM, true, false, 8>(a, N, counts, st);                \
+      default: return MP_ERR_UNSUPPORTED;                                                      \
+    }
+    if (w == 4) { MP_HEADS(4) } else if (w == 2) { MP_HEADS(2) } else { MP_HEADS(1) }
+#undef MP_HEADS
+  }
   const bool two = Q != nullptr;
   switch (w) {
     case 4: return two ? dispatch_reduce<4, true>(a, N, counts, reduce, st)
@@ -660,6 +691,14 @@ int mp_idgnn_agg_f32(const int32_t* rowptr, const int32_t* col_marked, const flo
   if (!Q) return MP_ERR_INVALID_ARG;
   return agg_common(rowptr, col_marked, val, N, plan, counts_host, X, ldx, P, ldp, Q, ldq, d, MP_SUM,
                     nullptr, 0, 0.f, nullptr, MP_ACT_NONE, nullptr, ws, ws_bytes, as_stream(stream));
+}
+
+int mp_spmm_csr_heads_f32(const int32_t* rowptr, const int32_t* col, const float* a, int64_t N, const int32_t* plan,
+                          const int32_t* counts_host, int32_t heads, const float* V, int64_t ldv, float* Y, int64_t ldy,
+                          int32_t d, void* ws, size_t ws_bytes, mp_stream_t stream) {
+  if (heads < 1 || !a) return MP_ERR_INVALID_ARG;
+  return agg_common(rowptr, col, a, N, plan, counts_host, V, ldv, Y, ldy, nullptr, 0, d, MP_SUM, nullptr, 0, 0.f,
+                    nullptr, MP_ACT_NONE, nullptr, ws, ws_bytes, as_stream(stream), nullptr, 0, 1e-12f, heads);
 }
 
 int mp_spmm_max_bwd_f32(const int32_t* col, const float* val, const int32_t* argmax, const float* dY,

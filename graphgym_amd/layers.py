@@ -338,9 +338,7 @@ class GATIDConvLayer(nn.Module):
         hv = h.view(-1, H, Cc)
         a_i = (hv * self.att[:, :, :Cc]).sum(dim=-1)          # [N, H]  destination part
         a_j = (hv * self.att[:, :, Cc:]).sum(dim=-1)          # [N, H]  source part
-        scores = torch.cat([ops.sddmm_add(g, a_i[:, k].contiguous(), a_j[:, k].contiguous(),
-                                          self.negative_slope) for k in range(H)], dim=1)
-        alpha = ops.edge_softmax(g, scores)
+        alpha = ops.gat_alpha(g, a_i, a_j, self.negative_slope)      # scores + row softmax, all heads, one launch
         alpha = F.dropout(alpha, p=self.dropout, training=self.training)
         out = ops.spmm_edge_values(g, alpha, h, H)
         if not self.concat:
@@ -483,9 +481,7 @@ class GATConvLayer(nn.Module):
         hv = h.view(-1, H, Cc)
         a_src = (hv * self.att_l).sum(dim=-1)
         a_dst = (hv * self.att_r).sum(dim=-1)
-        scores = torch.cat([ops.sddmm_add(g, a_dst[:, k].contiguous(), a_src[:, k].contiguous(),
-                                          self.negative_slope) for k in range(H)], dim=1)
-        alpha = F.dropout(ops.edge_softmax(g, scores), p=self.dropout, training=self.training)
+        alpha = F.dropout(ops.gat_alpha(g, a_dst, a_src, self.negative_slope), p=self.dropout, training=self.training)
         out = ops.spmm_edge_values(g, alpha, h, H)
         if not self.concat:
             out = out.view(-1, H, Cc).mean(dim=1)

@@ -371,9 +371,26 @@ def _raw_spmm_heads(g, a, V, heads):
     if heads == 1:   # one weight per entry: this is the hot aggregation kernel with val = a
         y, _ = _raw_spmm(g.with_values(a.reshape(-1).contiguous()), V, _lib.SUM)
         return y
+    if heads in (2, 4, 8) and V.size(1) % heads == 0:
+        # all heads in ONE launch of the hot kernel: full-row loads of V, every lane applies the weight of the head its
+        # columns belong to (mp_spmm_csr_heads_f32); round 1 ran one launch per head on column slices
+        L = lib()
+        N, d = g.num_nodes, V.size(1)
+        a = a.contiguous()
+        y = placement.empty_or_torch((N, d), V.device, reads=(V,))
+        plan, counts = g.plan()
+        with torch.cuda.device(V.device):
+            nb = C.c_size_t(0)
+            check(L.mp_spmm_ws_bytes(counts, d, _lib.SUM, 0, C.byref(nb)))
+            ws = torch.empty(nb.value, dtype=torch.uint8, device=V.device) if nb.value else None
+            st = L.mp_spmm_csr_heads_f32(ptr(g.rowptr), ptr(g.col), ptr(a), N, ptr(plan), counts, heads, ptr(V),
+                                         V.stride(0), ptr(y), y.stride(0), d, ptr(ws), nb.value, _stream())
+        if st == 0:
+            return y
+        if st != 2:
+            check(st, "mp_spmm_csr_heads_f32")
     if V.size(1) % heads == 0:
-        # H heads = H launches of the hot kernel on column slices (the ABI takes leading dimensions):
-        # head h aggregates V[:, h*dh:(h+1)*dh] with the entry values a[:, h]
+        # head layouts outside the one-launch kernel: one launch of the hot kernel per head on column slices
         dh = V.size(1) // heads
         y = torch.empty((g.num_nodes, V.size(1)), dtype=torch.float32, device=V.device)
         for h in range(heads):
@@ -444,6 +461,47 @@ class _SddmmAdd(torch.autograd.Function):
 
 def sddmm_add(g, ai, aj, slope=0.2):
     return _SddmmAdd.apply(ai, aj, g, float(slope))
+
+
+class _GatAlpha(torch.autograd.Function):
+    """alpha[e, h] = softmax over destination row of leaky_relu(a_dst[row_e, h] + a_src[col_e, h]): one launch for all
+    heads, scores never stored (mp_gat_alpha_f32)"""
+    @staticmethod
+    def forward(ctx, a_dst, a_src, g, slope):
+        L = lib()
+        ad = a_dst.contiguous().float()
+        asr = a_src.contiguous().float()
+        H = ad.size(1)
+        alpha = torch.empty((max(g.nnz, 1), H), dtype=torch.float32, device=ad.device)
+        with torch.cuda.device(ad.device):
+            check(L.mp_gat_alpha_f32(ptr(g.rowptr), ptr(g.col), g.num_nodes, g.nnz, H, ptr(ad), ptr(asr), float(slope),
+                                     ptr(alpha), _stream()), "mp_gat_alpha_f32")
+        alpha = alpha[:g.nnz]
+        ctx.g, ctx.slope = g, slope
+        ctx.save_for_backward(alpha, ad, asr)
+        return alpha
+
+    @staticmethod
+    def backward(ctx, dalpha):
+        alpha, ad, asr = ctx.saved_tensors
+        g, L = ctx.g, lib()
+        H = alpha.size(1)
+        dalpha = dalpha.contiguous()
+        ds = torch.empty_like(alpha)
+        with torch.cuda.device(alpha.device):
+            check(L.mp_csr_row_softmax_bwd_f32(ptr(g.rowptr), g.num_nodes, H, ptr(alpha), ptr(dalpha), ptr(ds),
+                                               _stream()), "mp_csr_row_softmax_bwd_f32")
+        rows, cols = g.row_ids().long(), g.col.long()
+        pre = ad[rows] + asr[cols]
+        ds = ds * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, ctx.slope))
+        d_dst = torch.zeros_like(ad).index_add_(0, rows, ds)
+        d_src = torch.zeros_like(asr).index_add_(0, cols, ds)
+        return d_dst, d_src, None, None
+
+
+def gat_alpha(g, a_dst, a_src, slope=0.2):
+    """additive attention coefficients [nnz, H] for per-node terms a_dst, a_src [N, H] (idconv.py:319-327)"""
+    return _GatAlpha.apply(a_dst, a_src, g, float(slope))
 
 
 class _EdgeSoftmax(torch.autograd.Function):

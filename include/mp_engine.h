@@ -394,6 +394,11 @@ int mp_sddmm_dot_stream_f32(const int32_t* row_of, const int32_t* col, int64_t n
 int mp_sddmm_add_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t nnz,
                      const float* ai, const float* aj, float slope, float* s,
                      mp_stream_t stream);
+/* additive attention coefficients in one pass, all heads (idconv.py:319-327; torch_geometric GATConv [3P]):
+ * alpha[e*H+h] = softmax over the entries e of row r of leaky_relu(a_dst[r*H+h] + a_src[col[e]*H+h], slope);
+ * the scores are never stored.  a_dst, a_src [N, H]. */
+int mp_gat_alpha_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t nnz, int32_t heads,
+                     const float* a_dst, const float* a_src, float slope, float* alpha, mp_stream_t stream);
 /* softmax over each row's entries, per head: segment_softmax (sparse_adj.py:136-151),
  * torch_geometric.utils.softmax (idconv.py:327).  In-place allowed. */
 int mp_csr_row_softmax_f32(const int32_t* rowptr, int64_t N, int32_t heads,
@@ -407,7 +412,14 @@ int mp_csr_row_softmax_bwd_f32(const int32_t* rowptr, int64_t N, int32_t heads,
 int mp_sddmm_grad_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t nnz,
                       const float* A, int64_t lda, const float* B, int64_t ldb,
                       int32_t d, int32_t heads, float* g, mp_stream_t stream);
-/* multi-head weighted aggregation: Y[r, slice h] = sum_e a[e*H+h] * V[col[e], slice h] */
+/* multi-head weighted aggregation on the segment plan — ALL heads in one launch of the hot kernel (full-row loads; a lane
+ * applies the weight of the head its columns belong to): Y[r, slice h] = sum_e a[e*H+h] * V[col[e], slice h]
+ * (TfgIDLayer.py:340-355 with split_value_heads; idconv.py:317-332).  heads in {1, 2, 4, 8}, d % heads == 0
+ * (MP_ERR_UNSUPPORTED otherwise: use mp_spmm_heads_f32).  Workspace as mp_spmm_csr_f32 (mp_spmm_ws_bytes, reduce SUM). */
+int mp_spmm_csr_heads_f32(const int32_t* rowptr, const int32_t* col, const float* a, int64_t N, const int32_t* plan,
+                          const int32_t* counts_host, int32_t heads, const float* V, int64_t ldv, float* Y, int64_t ldy,
+                          int32_t d, void* ws, size_t ws_bytes, mp_stream_t stream);
+/* the same without a plan (one wave per row; any head count): fallback for head layouts the plan kernel does not take */
 int mp_spmm_heads_f32(const int32_t* rowptr, const int32_t* col, const float* a,
                       int64_t N, int32_t heads, const float* V, int64_t ldv,
                       float* Y, int64_t ldy, int32_t d, mp_stream_t stream);

@@ -587,3 +587,63 @@ def test_by_source_normalisation_is_bitwise_reproducible(dev):
     ei_r, norm_r = R.pyg_gcn_norm(ei, N, w)
     ref = torch.zeros(N, N, dtype=torch.float64).index_put_((ei_r[1], ei_r[0]), norm_r.double(), accumulate=True)
     close(_dense(G), ref, 1e-5)
+
+
+@pytest.mark.parametrize("heads,d", [(2, 64), (4, 256), (8, 128), (4, 24)])
+def test_multi_head_aggregation_in_one_launch(dev, heads, d):
+    """Y[r, slice h] = sum_e a[e, h] V[col_e, slice h] for all heads in ONE launch of the plan-based kernel
+    (mp_spmm_csr_heads_f32), hub rows included, against float64; and the gradients of spmm_edge_values through it"""
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(heads * 100 + d)
+    N, E = 900, 14000
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :3000] = 17                                              # a hub row: pieces + finalize
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N)
+    a = torch.rand(G.nnz, heads, generator=g)
+    V = torch.randn(N, d, generator=g)
+    calls = []
+    from graphgym_amd import _lib
+    L = _lib.lib()
+    y = ops._raw_spmm_heads(G, a.to(dev), V.to(dev), heads)
+    rows, cols = G.row_ids().cpu().long(), G.col.cpu().long()
+    dh = d // heads
+    w = a.double().repeat_interleave(dh, dim=1)                    # [nnz, d]: head h's weight on its dh columns
+    ref = torch.zeros(N, d, dtype=torch.float64).index_add_(0, rows, w * V.double()[cols])
+    close(y, ref)
+    ad, Vd = a.to(dev).requires_grad_(True), V.to(dev).requires_grad_(True)
+    up = torch.randn(N, d, generator=g)
+    ops.spmm_edge_values(G, ad, Vd, heads).backward(up.to(dev))
+    ar, Vr = a.double().requires_grad_(True), V.double().requires_grad_(True)
+    torch.zeros(N, d, dtype=torch.float64).index_add_(
+        0, rows, ar.repeat_interleave(dh, dim=1) * Vr[cols]).backward(up.double())
+    close(ad.grad, ar.grad, 2e-5)
+    close(Vd.grad, Vr.grad, 2e-5)
+
+
+@pytest.mark.parametrize("heads", [1, 4])
+def test_additive_attention_coefficients_in_one_pass(dev, heads):
+    """alpha = softmax_row(leaky_relu(a_dst[row] + a_src[col])) for all heads in one launch (mp_gat_alpha_f32), forward
+    and the gradients to both per-node terms, against torch autograd through the oracle's softmax (idconv.py:319-327)"""
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(40 + heads)
+    N, E = 700, 9000
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :2500] = 3
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), N, remove_self_loops=True, add_self_loops=True)
+    rows, cols = G.row_ids().cpu().long(), G.col.cpu().long()
+    a_dst, a_src = torch.randn(N, heads, generator=g), torch.randn(N, heads, generator=g)
+    dal = torch.randn(G.nnz, heads, generator=g)
+    adg, asg = a_dst.to(dev).requires_grad_(True), a_src.to(dev).requires_grad_(True)
+    alpha = ops.gat_alpha(G, adg, asg, 0.2)
+    alpha.backward(dal.to(dev))
+    adr, asr = a_dst.double().requires_grad_(True), a_src.double().requires_grad_(True)
+    s = torch.nn.functional.leaky_relu(adr[rows] + asr[cols], 0.2)
+    ref = R.softmax(s, rows, N)
+    ref.backward(dal.double())
+    close(alpha, ref)
+    close(adg.grad, adr.grad, 2e-5)
+    close(asg.grad, asr.grad, 2e-5)
+    sums = torch.zeros(N, heads, dtype=torch.float64).index_add_(0, rows, alpha.detach().cpu().double())
+    assert float((sums - 1.0).abs().max()) <= 1e-5                  # every row has its self loop: coefficients sum to 1
