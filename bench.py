@@ -147,7 +147,7 @@ def run_aggregate(args, rank, world, dev):
     if x is None:
         x = torch.empty((n, d), dtype=torch.float32, device=dev)
     x.uniform_(-1.0, 1.0, generator=gen)
-    y = placement.empty_or_torch((n, d), dev, reads=(x,), verify=4)    # resident output: the 4 best predicted positions timed once
+    y = placement.empty_or_torch((n, d), dev, reads=(x,), verify="all")   # resident output: every free position timed once (~0.2 s of set-up)
     ar = placement.arena(dev, create=False)
     place = {"engine_placed": bool(ar is not None and ar.owns(y)), "x_in_arena": bool(x_engine),
              "predicted_conflict": getattr(y, "_mp_predicted_conflict", None),

@@ -35,6 +35,7 @@ GRANULE = 4 * GiB          # resolution of the conflict map
 CHUNK = 1 * GiB            # bytes copied per calibration probe (well past the 256 MiB Infinity Cache)
 FOREIGN_CHUNK = 512 << 20  # per probe of a tensor the engine did not allocate
 CALIBRATION_TRIALS = 3     # timed copies per pair of granules (the fastest counts)
+VERIFY_CHUNK = 512 << 20   # bytes per timed copy when candidate positions are verified
 MIN_BYTES = int(os.environ.get("MP_PLACE_MIN_MB", "1024")) << 20
 
 _lock = threading.Lock()
@@ -163,11 +164,12 @@ class Arena:
     # ---- allocation ---------------------------------------------------------------------
     def empty(self, shape, dtype=torch.float32, reads=(), weights=None, verify=0):
         """a tensor placed to conflict least with `reads` (weights default to their byte sizes); None when the
-        arena cannot hold it.  verify=k > 1: the k best predicted positions are each timed against the largest read
-        tensor (a 1 GiB copy, ~1 ms per candidate) and the fastest is kept — for long-lived buffers (a resident output
-        the same launch writes every step), where a few milliseconds of set-up buy the last per cent."""
-        if verify and verify > 1 and reads:
-            return self._empty_verified(shape, dtype, reads, weights, int(verify))
+        arena cannot hold it.  verify=k > 1: the k best predicted positions — verify="all": every free granule-aligned
+        position — are timed against sample chunks of the read tensors (a few ms per candidate) and the fastest is
+        kept: for long-lived buffers (a resident output the same launch writes every step), where 0.1 s of set-up buys the
+        last per cent over the prediction."""
+        if verify and (verify == "all" or verify > 1) and reads:
+            return self._empty_verified(shape, dtype, reads, weights, verify)
         code, bits, esize = _DL_TYPES[dtype]
         shape = tuple(int(s) for s in shape)
         nbytes = int(np.prod(shape, dtype=np.int64)) * esize
@@ -189,44 +191,88 @@ class Arena:
         if st == 3:       # MP_ERR_WORKSPACE: no free run of that size
             return None
         check(st, "mp_arena_alloc_placed")
-        managed = C.c_void_p()
-        sh = (C.c_int64 * len(shape))(*shape)
-        st = L.mp_arena_dlpack(out, len(shape), sh, code, bits, C.byref(managed))
-        if st != 0:
-            L.mp_arena_release(out)
-            check(st, "mp_arena_dlpack")
-        t = torch.from_dlpack(_PyCapsule_New(managed, _CAPSULE_NAME, None))
+        t = self._wrap(out.value, shape, dtype)
         if pen is not None:
             t._mp_predicted_conflict = float(self._footprint(out.value, nbytes) @ pen)
         return t
 
+    def _wrap(self, ptr, shape, dtype):
+        code, bits, _ = _DL_TYPES[dtype]
+        managed = C.c_void_p()
+        sh = (C.c_int64 * len(shape))(*shape)
+        st = lib().mp_arena_dlpack(C.c_void_p(ptr), len(shape), sh, code, bits, C.byref(managed))
+        if st != 0:
+            lib().mp_arena_release(C.c_void_p(ptr))
+            check(st, "mp_arena_dlpack")
+        return torch.from_dlpack(_PyCapsule_New(managed, _CAPSULE_NAME, None))
+
+    def empty_at(self, shape, granule, dtype=torch.float32):
+        """a tensor whose range starts in granule `granule` (None when that part of the arena is taken): for studies
+        and tests that compare positions"""
+        shape = tuple(int(s) for s in shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * _DL_TYPES[dtype][2]
+        span = max(1, -(-nbytes // GRANULE))
+        pen = np.ones(self.n_gran, dtype=np.float32)
+        pen[granule:granule + span] = 0.0
+        out = C.c_void_p()
+        st = lib().mp_arena_alloc_placed(nbytes, pen.ctypes.data_as(C.c_void_p), self.n_gran, GRANULE, C.byref(out))
+        if st != 0:
+            return None
+        if (out.value - self.base) // GRANULE != granule:
+            lib().mp_arena_release(out)
+            return None
+        return self._wrap(out.value, shape, dtype)
+
+    def _pair_ms(self, reads, t):
+        """timed copies between sample chunks of the read tensors and of the candidate: every (read sample, candidate
+        sample) pair, since a gather kernel reads all of its input while it writes each part of its output"""
+        tb = t.numel() * t.element_size()
+        pb = min(VERIFY_CHUNK, tb // 256 * 256)
+        if pb < (16 << 20):
+            return 0.0
+        def samples(base, nb):
+            k = 1 if nb < 2 * pb else 3
+            return [base + ((nb - pb) * i // max(k - 1, 1)) // 256 * 256 for i in range(k)]
+        total = 0.0
+        for r in reads:
+            nb = r.numel() * r.element_size()
+            if nb < pb:
+                continue
+            for src in samples(r.data_ptr(), nb):
+                for dst in samples(t.data_ptr(), tb):
+                    total += min(_probe(src, dst, pb, 1) for _ in range(2))
+        return total
+
     def _empty_verified(self, shape, dtype, reads, weights, k):
         reads = [r for r in reads if r is not None]
-        big = max(reads, key=lambda r: r.numel() * r.element_size())
-        nb = big.numel() * big.element_size()
-        probe_bytes = min(CHUNK, nb // 256 * 256)
-        cands, held = [], []
-        try:
-            for _ in range(k):
-                t = self.empty(shape, dtype, reads, weights)
-                if t is None:
-                    break
-                tb = t.numel() * t.element_size()
-                pb = min(probe_bytes, tb // 256 * 256)
-                # middle of the read tensor -> middle of the candidate, fastest of three
-                src = big.data_ptr() + (nb // 2 - pb // 2) // 256 * 256
-                dst = t.data_ptr() + (tb // 2 - pb // 2) // 256 * 256
-                ms = min(_probe(src, dst, pb, 1) for _ in range(3)) if pb >= (16 << 20) else 0.0
-                cands.append((ms, t))
-                # make the allocator look elsewhere next time: hold this candidate while the others are tried
-                held.append(t)
-            if not cands:
+        if k == "all":
+            timed = []                       # one candidate at a time: neighbouring positions overlap
+            for g in range(self.n_gran):
+                t = self.empty_at(shape, g, dtype)
+                if t is not None:
+                    timed.append((self._pair_ms(reads, t), g))
+                    del t
+            if not timed:
                 return None
-            best = min(cands, key=lambda c: c[0])[1]
-            best._mp_verified_candidates_ms = [c[0] for c in cands]
+            best = self.empty_at(shape, min(timed)[1], dtype)
+            if best is not None:
+                best._mp_verified_candidates_ms = [round(ms, 4) for ms, _ in timed]
             return best
-        finally:
-            del held, cands
+        cands = []
+        held = []
+        for _ in range(int(k)):     # the k best predicted positions: each candidate is held while the next is placed
+            t = self.empty(shape, dtype, reads, weights)
+            if t is None:
+                break
+            cands.append((self._pair_ms(reads, t), t))
+            held.append(t)
+        del held
+        if not cands:
+            return None
+        best = min(cands, key=lambda c: c[0])[1]
+        best._mp_verified_candidates_ms = [round(c[0], 4) for c in cands]
+        del cands
+        return best
 
     def stats(self):
         iu, lf = C.c_size_t(), C.c_size_t()

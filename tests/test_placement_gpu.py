@@ -48,54 +48,58 @@ def test_arena_tensors_behave_like_tensors(dev):
 
 
 def test_placed_output_is_within_3pct_of_the_best_pair(dev):
-    """X = 8 GiB read matrix, Y = placed output of the same size.  A timed copy X -> Y is compared with the fastest
-    copy from X into ANY free granule-aligned position of the arena (every position timed: fastest of two trials of
-    three launches):
-      * the verified placement (the k best predicted positions timed once against X, what bench.py uses for its
-        resident output) is within 3 % of the best pair;
-      * the predicted placement alone (what every operator output gets, no timing at allocation) is in the fast half of
-        the spread and within 6 % of the best pair;
+    """The thing placement is for, measured directly: the aggregation Y = A X (X = 4 GiB: 2^22 nodes x 256 fp32, BA graph)
+    is timed with Y at EVERY free granule-aligned position of the arena (fastest of three launches each).
+      * Y placed with verify="all" (what bench.py does for its resident output) is within 3 % of the best position;
+      * Y placed by prediction alone (what every operator output gets: no timing at allocation) is within 5 % of the
+        best and not in the slow half;
     and the worst position must actually be slower (otherwise the test proves nothing)."""
-    from graphgym_amd import placement
-    from graphgym_amd._lib import lib, check
+    import graphgym_amd as ga
+    from graphgym_amd import graphgen, ops, placement
     ar = placement.arena(dev)
-    n = 8 * GiB // (256 * 4)
-    x = ar.empty((n, 256))
+    n, d = 1 << 22, 256
+    ei = graphgen.ba_edge_index(n, 5, seed=3, device=dev)
+    g = ga.CSRGraph.from_edge_index(ei, n, add_self_loops=True).gcn_norm("row")
+    del ei
+    g.plan()
+    x = ar.empty((n, d))
     x.uniform_(-1, 1)
 
-    def timed(y):
-        return min(placement._probe(x.data_ptr(), y, 8 * GiB, 3) for _ in range(2))
+    def agg_ms(y):
+        ops._raw_spmm(g, x, 0, out=y)
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops._raw_spmm(g, x, 0, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
 
-    y = ar.empty((n, 256), reads=(x,))
+    y = ar.empty((n, d), reads=(x,))
     assert y is not None and ar.owns(y)
-    t_pred = timed(y.data_ptr())
+    t_pred = agg_ms(y)
     del y
     gc.collect()
-    yv = ar.empty((n, 256), reads=(x,), verify=4)
-    assert yv is not None and ar.owns(yv) and len(yv._mp_verified_candidates_ms) >= 2
-    t_ver = timed(yv.data_ptr())
+    yv = ar.empty((n, d), reads=(x,), verify="all")
+    assert yv is not None and ar.owns(yv) and len(yv._mp_verified_candidates_ms) >= 8
+    t_ver = agg_ms(yv)
     del yv
     gc.collect()
-    L = lib()
     times = []
-    for gidx in range(0, ar.n_gran - 1):
-        pen = np.ones(ar.n_gran, dtype=np.float32)
-        pen[gidx:gidx + 2] = 0.0
-        out = C.c_void_p()
-        st = L.mp_arena_alloc_placed(8 * GiB, pen.ctypes.data_as(C.c_void_p), ar.n_gran, placement.GRANULE,
-                                     C.byref(out))
-        if st != 0:
+    for gidx in range(ar.n_gran):
+        yc = ar.empty_at((n, d), gidx)
+        if yc is None:
             continue
-        try:
-            times.append(timed(out.value))
-        finally:
-            check(L.mp_arena_release(out))
+        times.append(agg_ms(yc))
+        del yc
     assert len(times) >= 8
     best, worst, median = min(times), max(times), sorted(times)[len(times) // 2]
-    assert worst >= 1.05 * best, f"no placement effect on this box? best {best:.3f} worst {worst:.3f}"
-    assert t_ver <= 1.03 * best, f"verified pair {t_ver:.3f} ms vs best {best:.3f} ms (worst {worst:.3f})"
-    assert t_pred <= 1.06 * best and t_pred <= median, \
-        f"predicted pair {t_pred:.3f} ms vs best {best:.3f} / median {median:.3f} / worst {worst:.3f}"
+    assert worst >= 1.04 * best, f"no placement effect on this box? best {best:.3f} worst {worst:.3f}"
+    assert t_ver <= 1.03 * best, f"verified placement {t_ver:.3f} ms vs best {best:.3f} ms (worst {worst:.3f})"
+    assert t_pred <= 1.05 * best and t_pred <= median, \
+        f"predicted placement {t_pred:.3f} ms vs best {best:.3f} / median {median:.3f} / worst {worst:.3f}"
 
 
 def test_ops_place_large_outputs_and_small_ones_stay_with_torch(dev):
