@@ -149,6 +149,17 @@ class CSRGraph:
                         None if self.val is None else self.val[idx].contiguous(), None,
                         rows.numel(), total, self.num_cols)
 
+    def edge_operator(self):
+        """[N, nnz] operator with one column per stored entry (entry e of row r -> column e, same value): reduces
+        per-entry messages [nnz, d] by destination on the aggregation kernel (messages that are not x_j alone, e.g.
+        x_j + edge_feature of generalconv.py:99-106)"""
+        g = self.__dict__.get("_edge_op")
+        if g is None:
+            cols = torch.arange(self.nnz, dtype=torch.int32, device=self.device)
+            g = CSRGraph(self.rowptr, cols, self.val, None, self.num_nodes, self.nnz, max(self.nnz, 1))
+            self.__dict__["_edge_op"] = g
+        return g
+
     def with_values(self, val):
         """same sparsity pattern (and plan / transpose pattern), other entry values"""
         g = CSRGraph(self.rowptr, self.col, val, self.eid, self.num_nodes, self.nnz, self.num_cols)

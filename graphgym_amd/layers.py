@@ -244,8 +244,6 @@ class GeneralConvLayer(nn.Module, _CachedEdgesMixin):
         self.cached_num_edges = None
 
     def forward(self, x, edge_index, edge_weight=None, edge_feature=None, holder=None):
-        if edge_feature is not None:
-            raise NotImplementedError("edge_feature messages are outside the accelerated path")
         if self.self_msg not in ('none', 'add', 'concat'):
             raise ValueError('self_msg {} not defined'.format(self.self_msg))
         if self.self_msg == 'concat':
@@ -256,7 +254,16 @@ class GeneralConvLayer(nn.Module, _CachedEdgesMixin):
                             fill=2.0 if self.improved else 1.0)
         else:
             g = self._graph(holder, edge_index, x.size(0), edge_weight, loops="none")
-        x_msg = ops.spmm(g, h, self.agg, bias=self.bias)
+        if edge_feature is None:
+            x_msg = ops.spmm(g, h, self.agg, bias=self.bias)
+        else:
+            # message = norm * (x_j + edge_feature) (generalconv.py:99-106): per-entry messages [nnz, d_out], reduced by
+            # destination on the aggregation kernel through the one-column-per-entry operator
+            if edge_feature.size(0) != g.nnz or bool((g.eid < 0).any()):
+                raise RuntimeError("edge_feature has {} rows, the operator has {} entries (self loops were added or "
+                                   "removed: the reference fails here too)".format(edge_feature.size(0), g.nnz))
+            msg = ops.gather_rows(h, g.col.long()) + edge_feature[g.eid.long()]
+            x_msg = ops.spmm(g.edge_operator(), msg, self.agg, bias=self.bias)
         if self.self_msg == 'none':
             return x_msg
         if self.self_msg == 'add':

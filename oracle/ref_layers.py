@@ -167,7 +167,7 @@ def generalid_conv(x, edge_index, id_index, weight, weight_id, bias=None, agg="a
 
 
 def general_conv(x, edge_index, weight, weight_self=None, bias=None, agg="add", normalize_adj=False,
-                 self_msg="concat", improved=False, edge_weight=None):
+                 self_msg="concat", improved=False, edge_weight=None, edge_feature=None):
     """GeneralConvLayer.forward (generalconv.py:62-97)"""
     if self_msg == "concat":
         x_self = x @ weight_self
@@ -176,7 +176,7 @@ def general_conv(x, edge_index, weight, weight_self=None, bias=None, agg="add", 
         edge_index, norm = R.pyg_gcn_norm(edge_index, h.size(0), edge_weight, improved)
     else:
         norm = edge_weight
-    x_msg = R.propagate(edge_index, h, agg, norm)
+    x_msg = R.propagate(edge_index, h, agg, norm, edge_feature)
     if bias is not None:
         x_msg = x_msg + bias                                    # update(), generalconv.py:107-110
     if self_msg == "none":

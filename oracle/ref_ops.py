@@ -194,10 +194,13 @@ def softmax(src, index, num_nodes):
     return out / (den[index] + 1e-16)
 
 
-def propagate(edge_index, x, aggr, norm=None):
+def propagate(edge_index, x, aggr, norm=None, edge_feature=None):
     """MessagePassing.propagate [3P] for message = norm * x_j (idconv.py:91-92,179-180,238-239):
-    gather x_j = x[edge_index[0]], scale, scatter over edge_index[1]"""
+    gather x_j = x[edge_index[0]], scale, scatter over edge_index[1]; with edge_feature the message is
+    norm * (x_j + edge_feature) (generalconv.py:99-106)"""
     x_j = x[edge_index[0]]
+    if edge_feature is not None:
+        x_j = x_j + edge_feature
     msg = norm.view(-1, 1) * x_j if norm is not None else x_j
     return scatter(msg, edge_index[1], x.size(0), aggr)
 
