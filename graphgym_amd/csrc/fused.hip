@@ -34,6 +34,7 @@
 namespace mp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct FusedArgs {
   const int32_t* rowptr; const int32_t* col; const float* val;
@@ -41,6 +42,7 @@ struct FusedArgs {
   const float* X; int64_t ldx;
   const float* S; int64_t lds; float self_scale;
   const float* Wm; int64_t ldw;
+  const __bf16* Wsp; int64_t ldws;   // BF16X3: W^T split three ways into bf16, [3][dout][ldws = F]; see mfma_half_bf16x3
   const float* bias; int32_t act;
   const uint8_t* defer_act;   // [N] or NULL: rows with a nonzero flag are stored without the activation
   float* P; int64_t ldp;
@@ -86,10 +88,71 @@ __device__ __forceinline__ void mfma_half(const float (*T)[FH + 4], const float*
   }
 }
 
+// The same K half on the bf16 matrix pipe, fp32-accurate: every operand is split three ways, x = x0 + x1 + x2 with
+// x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (24 mantissa bits in all), and the product keeps the six
+// terms down to 2^-24 of the result: x0 y0 + x0 y1 + x1 y0 + x0 y2 + x1 y1 + x2 y0, each a v_mfma_f32_32x32x16_bf16
+// accumulating in fp32 (a bf16 x bf16 product is exact in fp32).  gfx950 runs f32 MFMA at 1/16 of the bf16 rate, so six
+// bf16 MFMAs of K = 16 replace eight f32 MFMAs of K = 2 at 3/8 of the cycles: the layer's MFMA cycles, which add almost
+// one for one to its gather time, shrink 2.7x.  A is split on the fly from the fp32 LDS tile (VALU work
+// that hides behind the MFMAs); W arrives pre-split and transposed ([3][dout][F] bf16, k contiguous: one 16-byte load
+// per lane, tile and split per K = 16 group), fetched one group ahead.
+template <int FH>
+__device__ __forceinline__ void mfma_half_bf16x3(const float (*T)[FH + 4], const __bf16* __restrict__ w0,
+                                                 const __bf16* __restrict__ w1, int64_t plane, f32x16& acc0,
+                                                 f32x16& acc1, int fr, int kk) {
+  // w0 / w1: this lane's column of tile 0 / tile 1 in split plane 0, already at k = k0 + 8 kk; `plane` = dout * F.
+  // One register slot per (tile, plane); a plane's registers are refilled for the next K group as soon as its last MFMA
+  // of this group has been issued (plane 2 is used once, plane 1 twice, plane 0 three times, in that order), so the
+  // loads run one group ahead without a second buffer (a double buffer spills at four waves per SIMD).
+  bf16x8 bq[2][3];
+  auto fetch = [&](int sp, int g) {
+    bq[0][sp] = *reinterpret_cast<const bf16x8*>(w0 + sp * plane + 16 * g);
+    bq[1][sp] = *reinterpret_cast<const bf16x8*>(w1 + sp * plane + 16 * g);
+  };
+  fetch(2, 0); fetch(1, 0); fetch(0, 0);
+#pragma unroll
+  for (int g = 0; g < FH / 16; ++g) {
+    const bool more = g + 1 < FH / 16;
+    const f32x4 alo = *reinterpret_cast<const f32x4*>(&T[fr][16 * g + 8 * kk]);
+    const f32x4 ahi = *reinterpret_cast<const f32x4*>(&T[fr][16 * g + 8 * kk + 4]);
+    bf16x8 a0, a1, a2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x = i < 4 ? alo[i] : ahi[i - 4];
+      const __bf16 b0 = (__bf16)x;
+      const float r1 = x - (float)b0;
+      const __bf16 b1 = (__bf16)r1;
+      const float r2 = r1 - (float)b1;
+      a0[i] = b0; a1[i] = b1; a2[i] = (__bf16)r2;
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[0][2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[1][2], acc1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) fetch(2, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[0][1], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[1][1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[0][1], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[1][1], acc1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) fetch(1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq[0][0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq[1][0], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[0][0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[1][0], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[0][0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[1][0], acc1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) fetch(0, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // W: floats per lane of one K half (half width FH = 64 W); KH: K halves (F = KH * FH); NCB: output column blocks of
 // 256 whose accumulators stay live across the halves (KH == 2 only; KH == 1 walks the blocks one after another);
 // PF: W fragments fetched PF K-groups ahead; NT_OUT: non-temporal stores of out
-template <int W, bool WEIGHTED, int U, int KH, int NCB, int PF, bool NT_OUT>
+template <int W, bool WEIGHTED, int U, int KH, int NCB, int PF, bool NT_OUT, bool BF16X3>
 __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(FusedArgs a) {
   constexpr int FH = kWave * W;
   constexpr int LDT = FH + 4;   // row stride of the tile: 16-byte aligned rows, conflict-free b128 fragment reads
@@ -288,11 +351,17 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
         const int n0 = cb + wave * 64;
         if (n0 >= a.dout) break;                       // wave-uniform
         const int cpair = n0 + 2 * fr;
-        const float* __restrict__ wp = a.Wm + (int64_t)(4 * kk) * a.ldw + (cpair < a.dout ? cpair : a.dout - 2);
+        const int ccol = cpair < a.dout ? cpair : a.dout - 2;
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        mfma_half<FH, PF>(T, wp, a.ldw, acc0, acc1, fr, kk);
+        if constexpr (BF16X3) {
+          const __bf16* w0 = a.Wsp + (int64_t)ccol * a.ldws + 8 * kk;
+          mfma_half_bf16x3<FH>(T, w0, w0 + a.ldws, (int64_t)a.dout * a.ldws, acc0, acc1, fr, kk);
+        } else {
+          const float* __restrict__ wp = a.Wm + (int64_t)(4 * kk) * a.ldw + ccol;
+          mfma_half<FH, PF>(T, wp, a.ldw, acc0, acc1, fr, kk);
+        }
         store_block(acc0, acc1, n0);
       }
     } else {
@@ -301,9 +370,14 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
         const int n0 = b * 64 * kWavesPerBlock + wave * 64;
         if (n0 < a.dout) {                             // wave-uniform
           const int cpair = n0 + 2 * fr;
-          const float* __restrict__ wp =
-              a.Wm + (int64_t)(k0 + 4 * kk) * a.ldw + (cpair < a.dout ? cpair : a.dout - 2);
-          mfma_half<FH, PF>(T, wp, a.ldw, acc[b][0], acc[b][1], fr, kk);
+          const int ccol = cpair < a.dout ? cpair : a.dout - 2;
+          if constexpr (BF16X3) {
+            const __bf16* w0 = a.Wsp + (int64_t)ccol * a.ldws + k0 + 8 * kk;
+            mfma_half_bf16x3<FH>(T, w0, w0 + a.ldws, (int64_t)a.dout * a.ldws, acc[b][0], acc[b][1], fr, kk);
+          } else {
+            const float* __restrict__ wp = a.Wm + (int64_t)(k0 + 4 * kk) * a.ldw + ccol;
+            mfma_half<FH, PF>(T, wp, a.ldw, acc[b][0], acc[b][1], fr, kk);
+          }
         }
       }
       if (kh + 1 < KH) __syncthreads();   // every wave has read T before the next half re-initialises it
@@ -321,8 +395,13 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
 template <int W, int KH, int NCB, int PF>
 static int launch_fused(const FusedArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)ceil_div(a.N, kTileRows)), block(kBlock);
-  if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, 8, KH, NCB, PF, false>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((agg_dense_kernel<W, false, 8, KH, NCB, PF, false>), grid, block, 0, st, a);
+  if (a.Wsp != nullptr) {
+    if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, 8, KH, NCB, PF, false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((agg_dense_kernel<W, false, 8, KH, NCB, PF, false, true>), grid, block, 0, st, a);
+  } else {
+    if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, 8, KH, NCB, PF, false, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((agg_dense_kernel<W, false, 8, KH, NCB, PF, false, false>), grid, block, 0, st, a);
+  }
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -369,8 +448,9 @@ extern "C" {
 int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
                      const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale, const float* W,
                      int64_t ldw, int32_t d_out, const float* bias, int act, const uint8_t* defer_act, float* P,
-                     int64_t ldp, float* out, int64_t ldo, mp_stream_t stream) {
+                     int64_t ldp, float* out, int64_t ldo, const void* W_split, mp_stream_t stream) {
   if (!rowptr || !X || !W || !out || N < 0 || F <= 0 || d_out <= 0) return MP_ERR_INVALID_ARG;
+  if (W_split && ((uintptr_t)W_split % 16)) return MP_ERR_ALIGNMENT;
   if (ldx < F || ldw < d_out || ldo < d_out || (S && lds < F) || (P && ldp < F)) return MP_ERR_INVALID_ARG;
   if (act != MP_ACT_NONE && act != MP_ACT_RELU) return MP_ERR_INVALID_ARG;
   if (reduce != MP_SUM && reduce != MP_MEAN) return MP_ERR_INVALID_ARG;
@@ -390,6 +470,7 @@ int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val
   a.rowptr = rowptr; a.col = col; a.val = val; a.N = (int32_t)N;
   a.X = X; a.ldx = ldx; a.S = S; a.lds = lds; a.self_scale = self_scale;
   a.Wm = W; a.ldw = ldw; a.bias = bias; a.act = act; a.defer_act = defer_act;
+  a.Wsp = reinterpret_cast<const __bf16*>(W_split); a.ldws = F;
   a.P = P; a.ldp = ldp; a.out = out; a.ldo = ldo; a.dout = d_out; a.mean = reduce == MP_MEAN;
   a.out_vec4 = !mis(out, ldo, 16);
   hipStream_t st = as_stream(stream);

@@ -115,13 +115,39 @@ def agg_dense_supported(g, x, W):
             and g.nnz > 0 and g.max_row_entries() <= FUSED_MAX_ROW)
 
 
+BF16X3_MIN_ROWS = 16384     # below this the layer is launch-bound and the split's few small launches do not pay
+_split_cache = {}
+
+
+def _split_bf16_t(W):
+    """W [F, d] fp32 -> [3, d, F] bf16: W^T split three ways, plane s = bf16(W^T - sum of the planes before it)
+    (24 mantissa bits in all), the B operand of the bf16x3 product of mp_agg_dense_f32; cached per weight version"""
+    key = (W.data_ptr(), tuple(W.shape), W._version)
+    hit = _split_cache.get("k")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    Wt = W.detach().t().contiguous().float()
+    w0 = Wt.to(torch.bfloat16)
+    r1 = Wt - w0.float()
+    w1 = r1.to(torch.bfloat16)
+    w2 = (r1 - w1.float()).to(torch.bfloat16)
+    sp = torch.stack([w0, w1, w2]).contiguous()
+    _split_cache["k"] = (key, sp, W)        # holding W keeps its address from being reused under a stale key
+    return sp
+
+
 def _raw_agg_dense(g, x, W, bias=None, relu=False, S=None, self_scale=0.0, want_P=False, reduce=_lib.SUM,
-                   out=None, defer_act=None):
+                   out=None, defer_act=None, bf16x3=None):
     """out = act((reduce_j w_ij x[j] + self_scale * S) W + bias) in one launch (into the view `out` when given);
-    returns (out, P or None) with P the aggregated rows; defer_act [N] uint8: rows stored without the activation"""
+    returns (out, P or None) with P the aggregated rows; defer_act [N] uint8: rows stored without the activation.
+    bf16x3: run the product on the bf16 matrix pipe with three-way split operands (fp32-accurate, 3/8 of the MFMA
+    cycles); default: on for N >= BF16X3_MIN_ROWS unless MP_BF16X3=0."""
     L = lib()
     N, F, d = g.num_nodes, x.size(1), W.size(1)
     Wc = W.contiguous()
+    if bf16x3 is None:
+        bf16x3 = N >= BF16X3_MIN_ROWS and os.environ.get("MP_BF16X3", "1") != "0"
+    Wsp = _split_bf16_t(Wc) if bf16x3 else None
     b = None if bias is None else bias.contiguous()
     if out is None:
         out = placement.empty_or_torch((N, d), x.device, reads=(x,))
@@ -130,7 +156,8 @@ def _raw_agg_dense(g, x, W, bias=None, relu=False, S=None, self_scale=0.0, want_
         check(L.mp_agg_dense_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val), N, reduce, ptr(x), x.stride(0), F,
                                  ptr(S), S.stride(0) if S is not None else 0, float(self_scale), ptr(Wc),
                                  Wc.stride(0), d, ptr(b), _lib.ACT_RELU if relu else _lib.ACT_NONE, ptr(defer_act),
-                                 ptr(P), P.stride(0) if P is not None else 0, ptr(out), out.stride(0), _stream()),
+                                 ptr(P), P.stride(0) if P is not None else 0, ptr(out), out.stride(0), ptr(Wsp),
+                                 _stream()),
               "mp_agg_dense_f32")
     return out, P
 

@@ -297,11 +297,15 @@ int mp_bn_train_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t l
  * MP_ERR_UNSUPPORTED otherwise: use mp_spmm_csr_f32 + mp_dense_fused_f32).  P (optional, [N, F]) receives the
  * aggregated rows (kept for the weight gradient).  defer_act (optional, [N] uint8): rows with a nonzero flag are
  * stored WITHOUT the activation (mp_id_fixup_f32 finishes them).  A sign-bit identity mark on col
- * (mp_mark_id_sources) is ignored.  No plan, no workspace, no process-wide state; bitwise reproducible. */
+ * (mp_mark_id_sources) is ignored.  No plan, no workspace, no process-wide state; bitwise reproducible.
+ * W_split (optional): W^T split three ways into bf16 — [3][d_out][F] bf16, plane s holding
+ * bf16(W^T - sum of the planes before it) — switches the product to the bf16 matrix pipe with all six significant
+ * cross terms (fp32-accurate to ~2^-24 of the result; 3/8 of the MFMA cycles of the exact-fp32 form, which gfx950 runs at
+ * 1/16 of the bf16 rate).  NULL = v_mfma_f32_32x32x2_f32 on W itself. */
 int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
                      const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale, const float* W,
                      int64_t ldw, int32_t d_out, const float* bias, int act, const uint8_t* defer_act, float* P,
-                     int64_t ldp, float* out, int64_t ldo, mp_stream_t stream);
+                     int64_t ldp, float* out, int64_t ldo, const void* W_split, mp_stream_t stream);
 
 /* The identity branch of the ID layers on top of mp_agg_dense_f32: out = act(A (X W + S X W_id) + b)
  * (gcn_id, TfgIDLayer.py:510-523; GCNIDConvLayer.forward, idconv.py:150-177) equals

@@ -88,7 +88,9 @@ rec("dense_fused (P W + b, ReLU)", t, tflop=2.0 * n * d * d / 1e12)
 t = timeit(lambda: ops._raw_dense_wgrad(x, y, want_bias=True))
 rec("dense_wgrad (+ bias gradient)", t, tflop=2.0 * n * d * d / 1e12)
 t = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True, out=y))
-rec("agg_dense (aggregate -> transform, one kernel)", t, agg_bytes, tflop=2.0 * n * d * d / 1e12, note="moves the aggregation's bytes AND does the transform's flops")
+rec("agg_dense (aggregate -> transform, one kernel; bf16x3 product)", t, agg_bytes, tflop=2.0 * n * d * d / 1e12, note="moves the aggregation's bytes AND does the transform's flops (fp32-accurate three-way bf16 split on the bf16 matrix pipe)")
+t = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True, out=y, bf16x3=False))
+rec("agg_dense, exact-f32 MFMA product (round 1's form)", t, agg_bytes, tflop=2.0 * n * d * d / 1e12)
 # the ID layer: act(A (x W + S x W_id) + b), 1 % identity nodes
 Wid = torch.randn(d, d, device=dev) * 0.05
 with torch.no_grad():

@@ -107,7 +107,7 @@ def test_agg_dense_falls_back_outside_its_shapes(dev):
     from graphgym_amd._lib import lib, ptr
     x, W, out = torch.randn(n, 48, device=dev), torch.randn(48, 32, device=dev), torch.empty(n, 32, device=dev)
     st = lib().mp_agg_dense_f32(ptr(G.rowptr), ptr(G.col), ptr(G.val), n, 0, ptr(x), 48, 48, None, 0, 0.0, ptr(W), 32,
-                                32, None, 0, None, None, 0, ptr(out), 32, None)
+                                32, None, 0, None, None, 0, ptr(out), 32, None, None)
     assert st == 2                                                # MP_ERR_UNSUPPORTED
 
 
@@ -368,3 +368,30 @@ def test_id_layers_take_one_launch(dev):
         close(a, b)
     finally:
         ops._raw_agg_dense = orig
+
+
+@pytest.mark.parametrize("n,E,F,d,weighted,hubs", [(3000, 40000, 256, 256, True, True), (1000, 9000, 128, 64, False, False),
+                                                    (800, 9000, 512, 512, True, False), (500, 3000, 64, 130, True, False)])
+def test_bf16x3_product_is_fp32_accurate(dev, n, E, F, d, weighted, hubs):
+    """the one-kernel layer on the bf16 matrix pipe with three-way split operands (six cross terms) against float64, held
+    to the same 1e-5 as the exact-fp32 MFMA form, and within a few ulp of that form; weights with a wide dynamic range"""
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    ei, w = make_graph(n, E, seed=n + F + 7, hubs=hubs, weighted=weighted)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n, F, generator=gen) * torch.exp(torch.randn(n, 1, generator=gen))       # rows of different scales
+    W = torch.randn(F, d, generator=gen) / F ** 0.5 * torch.exp(torch.randn(1, d, generator=gen))
+    b = torch.randn(d, generator=gen)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, None if w is None else w.to(dev), dst_row=0)
+    exact, _ = ops._raw_agg_dense(G, x.to(dev), W.to(dev), b.to(dev), False, bf16x3=False)
+    split, _ = ops._raw_agg_dense(G, x.to(dev), W.to(dev), b.to(dev), False, bf16x3=True)
+    agg = torch.zeros(n, F, dtype=torch.float64).index_add_(
+        0, ei[0], x.double()[ei[1]] * (w.double().unsqueeze(1) if w is not None else 1.0))
+    ref = agg @ W.double() + b.double()
+    from _tol import assert_close_rows
+    assert_close_rows(split, ref, 1e-5, ref32=exact, what="bf16x3 vs float64")
+    e_split = float((split.cpu().double() - ref).abs().max())
+    e_exact = float((exact.cpu().double() - ref).abs().max())
+    assert e_split <= 4 * e_exact + 1e-7 * float(ref.abs().max()), (e_split, e_exact)
+    split2, _ = ops._raw_agg_dense(G, x.to(dev), W.to(dev), b.to(dev), False, bf16x3=True)
+    assert torch.equal(split, split2)
