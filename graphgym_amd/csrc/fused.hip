@@ -42,7 +42,7 @@ struct FusedArgs {
   const float* X; int64_t ldx;
   const float* S; int64_t lds; float self_scale;
   const float* Wm; int64_t ldw;
-  const __bf16* Wsp; int64_t ldws;   // BF16X3: W^T split three ways into bf16, [3][dout][ldws = F]; see mfma_half_bf16x3
+  const __bf16* Wsp; int64_t ldws;   // BF16X3: W split three ways into bf16, [3][F / 8][dout][8], ldws = F; see mfma_half_bf16x3
   const float* bias; int32_t act;
   const uint8_t* defer_act;   // [N] or NULL: rows with a nonzero flag are stored without the activation
   float* P; int64_t ldp;
@@ -94,20 +94,24 @@ __device__ __forceinline__ void mfma_half(const float (*T)[FH + 4], const float*
 // accumulating in fp32 (a bf16 x bf16 product is exact in fp32).  gfx950 runs f32 MFMA at 1/16 of the bf16 rate, so six
 // bf16 MFMAs of K = 16 replace eight f32 MFMAs of K = 2 at 3/8 of the cycles: the layer's MFMA cycles, which add almost
 // one for one to its gather time, shrink 2.7x.  A is split on the fly from the fp32 LDS tile (VALU work
-// that hides behind the MFMAs); W arrives pre-split and transposed ([3][dout][F] bf16, k contiguous: one 16-byte load
-// per lane, tile and split per K = 16 group), fetched one group ahead.
+// that hides behind the MFMAs); W arrives pre-split in the layout [3][F / 8][dout][8] bf16: the 8 k-values a lane feeds to
+// one MFMA are 16 contiguous bytes, and neighbouring columns are neighbours in memory, so a half-wave's loads of its two
+// interleaved column tiles cover 1 KiB contiguously (a [dout][F] layout, k contiguous per column, put every lane on its
+// own cache line: 8x over-fetch from L2 and the kernel ran 1.4x SLOWER than the f32 form).  Fetched one group ahead.
 template <int FH>
 __device__ __forceinline__ void mfma_half_bf16x3(const float (*T)[FH + 4], const __bf16* __restrict__ w0,
-                                                 const __bf16* __restrict__ w1, int64_t plane, f32x16& acc0,
-                                                 f32x16& acc1, int fr, int kk) {
-  // w0 / w1: this lane's column of tile 0 / tile 1 in split plane 0, already at k = k0 + 8 kk; `plane` = dout * F.
+                                                 int64_t gstride, int64_t plane, f32x16& acc0, f32x16& acc1, int fr,
+                                                 int kk) {
+  // w0: this lane's column pair (tile 0 = first 8 values, tile 1 = the next 8) in split plane 0 at K group 0 of this
+  // half; `gstride` = 2 * dout * 8 elements per K = 16 group; `plane` = dout * F elements per split plane.
+  const __bf16* __restrict__ w1 = w0 + 8;
   // One register slot per (tile, plane); a plane's registers are refilled for the next K group as soon as its last MFMA
   // of this group has been issued (plane 2 is used once, plane 1 twice, plane 0 three times, in that order), so the
   // loads run one group ahead without a second buffer (a double buffer spills at four waves per SIMD).
   bf16x8 bq[2][3];
   auto fetch = [&](int sp, int g) {
-    bq[0][sp] = *reinterpret_cast<const bf16x8*>(w0 + sp * plane + 16 * g);
-    bq[1][sp] = *reinterpret_cast<const bf16x8*>(w1 + sp * plane + 16 * g);
+    bq[0][sp] = *reinterpret_cast<const bf16x8*>(w0 + sp * plane + g * gstride);
+    bq[1][sp] = *reinterpret_cast<const bf16x8*>(w1 + sp * plane + g * gstride);
   };
   fetch(2, 0); fetch(1, 0); fetch(0, 0);
 #pragma unroll
@@ -356,8 +360,8 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
         if constexpr (BF16X3) {
-          const __bf16* w0 = a.Wsp + (int64_t)ccol * a.ldws + 8 * kk;
-          mfma_half_bf16x3<FH>(T, w0, w0 + a.ldws, (int64_t)a.dout * a.ldws, acc0, acc1, fr, kk);
+          const __bf16* w0 = a.Wsp + ((int64_t)kk * a.dout + ccol) * 8;
+          mfma_half_bf16x3<FH>(T, w0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, acc0, acc1, fr, kk);
         } else {
           const float* __restrict__ wp = a.Wm + (int64_t)(4 * kk) * a.ldw + ccol;
           mfma_half<FH, PF>(T, wp, a.ldw, acc0, acc1, fr, kk);
@@ -372,8 +376,8 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
           const int cpair = n0 + 2 * fr;
           const int ccol = cpair < a.dout ? cpair : a.dout - 2;
           if constexpr (BF16X3) {
-            const __bf16* w0 = a.Wsp + (int64_t)ccol * a.ldws + k0 + 8 * kk;
-            mfma_half_bf16x3<FH>(T, w0, w0 + a.ldws, (int64_t)a.dout * a.ldws, acc[b][0], acc[b][1], fr, kk);
+            const __bf16* w0 = a.Wsp + ((int64_t)(k0 / 8 + kk) * a.dout + ccol) * 8;
+            mfma_half_bf16x3<FH>(T, w0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, acc[b][0], acc[b][1], fr, kk);
           } else {
             const float* __restrict__ wp = a.Wm + (int64_t)(k0 + 4 * kk) * a.ldw + ccol;
             mfma_half<FH, PF>(T, wp, a.ldw, acc[b][0], acc[b][1], fr, kk);

@@ -120,18 +120,20 @@ _split_cache = {}
 
 
 def _split_bf16_t(W):
-    """W [F, d] fp32 -> [3, d, F] bf16: W^T split three ways, plane s = bf16(W^T - sum of the planes before it)
-    (24 mantissa bits in all), the B operand of the bf16x3 product of mp_agg_dense_f32; cached per weight version"""
+    """W [F, d] fp32 -> [3, F / 8, d, 8] bf16: W split three ways, plane s = bf16(W - sum of the planes before it)
+    (24 mantissa bits in all), in the layout the bf16x3 product of mp_agg_dense_f32 loads (a lane's 8 k-values of a
+    column contiguous, neighbouring columns neighbours); cached per weight version"""
     key = (W.data_ptr(), tuple(W.shape), W._version)
     hit = _split_cache.get("k")
     if hit is not None and hit[0] == key:
         return hit[1]
-    Wt = W.detach().t().contiguous().float()
-    w0 = Wt.to(torch.bfloat16)
-    r1 = Wt - w0.float()
+    Wf = W.detach().float()
+    F, d = Wf.shape
+    w0 = Wf.to(torch.bfloat16)
+    r1 = Wf - w0.float()
     w1 = r1.to(torch.bfloat16)
     w2 = (r1 - w1.float()).to(torch.bfloat16)
-    sp = torch.stack([w0, w1, w2]).contiguous()
+    sp = torch.stack([w0, w1, w2]).view(3, F // 8, 8, d).permute(0, 1, 3, 2).contiguous()
     _split_cache["k"] = (key, sp, W)        # holding W keeps its address from being reused under a stale key
     return sp
 

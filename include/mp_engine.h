@@ -298,8 +298,8 @@ int mp_bn_train_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t l
  * aggregated rows (kept for the weight gradient).  defer_act (optional, [N] uint8): rows with a nonzero flag are
  * stored WITHOUT the activation (mp_id_fixup_f32 finishes them).  A sign-bit identity mark on col
  * (mp_mark_id_sources) is ignored.  No plan, no workspace, no process-wide state; bitwise reproducible.
- * W_split (optional): W^T split three ways into bf16 — [3][d_out][F] bf16, plane s holding
- * bf16(W^T - sum of the planes before it) — switches the product to the bf16 matrix pipe with all six significant
+ * W_split (optional): W split three ways into bf16 — [3][F / 8][d_out][8] bf16 (element [s][k / 8][c][k % 8] =
+ * plane s of W[k][c]), plane s holding bf16(W - sum of the planes before it) — switches the product to the bf16 matrix pipe with all six significant
  * cross terms (fp32-accurate to ~2^-24 of the result; 3/8 of the MFMA cycles of the exact-fp32 form, which gfx950 runs at
  * 1/16 of the bf16 rate).  NULL = v_mfma_f32_32x32x2_f32 on W itself. */
 int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
