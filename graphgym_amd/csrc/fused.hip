@@ -52,6 +52,9 @@ struct FusedArgs {
 };
 
 constexpr int kTileRows = 32;
+#ifndef MP_FUSED_U
+#define MP_FUSED_U 16   // neighbour rows in flight per wave in phase A
+#endif
 
 // one K half of phase B: acc += T[32 x FH] * W[k0 : k0 + FH, 64 columns of this wave]
 // K is walked in groups of 8: hardware k-slot kk (= lane >> 5) of MFMA j takes k = 8 g + 4 kk + j, so a
@@ -400,11 +403,11 @@ template <int W, int KH, int NCB, int PF>
 static int launch_fused(const FusedArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)ceil_div(a.N, kTileRows)), block(kBlock);
   if (a.Wsp != nullptr) {
-    if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, 8, KH, NCB, PF, false, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((agg_dense_kernel<W, false, 8, KH, NCB, PF, false, true>), grid, block, 0, st, a);
+    if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, MP_FUSED_U, KH, NCB, PF, false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((agg_dense_kernel<W, false, MP_FUSED_U, KH, NCB, PF, false, true>), grid, block, 0, st, a);
   } else {
-    if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, 8, KH, NCB, PF, false, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((agg_dense_kernel<W, false, 8, KH, NCB, PF, false, false>), grid, block, 0, st, a);
+    if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, MP_FUSED_U, KH, NCB, PF, false, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((agg_dense_kernel<W, false, MP_FUSED_U, KH, NCB, PF, false, false>), grid, block, 0, st, a);
   }
   MP_LAUNCH_CHECK();
   return MP_OK;
