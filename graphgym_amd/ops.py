@@ -115,7 +115,7 @@ def agg_dense_supported(g, x, W):
             and g.nnz > 0 and g.max_row_entries() <= FUSED_MAX_ROW)
 
 
-BF16X3_MIN_ROWS = 16384     # below this the layer is launch-bound and the split's few small launches do not pay
+BF16X3_MIN_ROWS = 1 << 19   # below this the split of W (a few small launches per call) costs more than the shorter MFMA phase saves
 _split_cache = {}
 
 
