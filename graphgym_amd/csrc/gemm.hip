@@ -166,7 +166,20 @@ __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(co
 // RELU: the backward of a ReLU epilogue rides along — g is masked by [Y > 0] (Y = the forward output) on its way to
 // LDS, and the blocks of the first f-tile also write the masked gradient GM (what the input-gradient launch reads):
 // the separate masking pass (30 GB at 10^7 x 256) disappears into a pass that is bound by its MFMA work.
-template <bool VEC, bool RELU>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = s0 + s1 + s2 with s0 = bf16(x), s1 = bf16(x - s0), s2 = bf16(x - s0 - s1): 24 mantissa bits in three bf16 values
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& s0, bf16x8& s1, bf16x8& s2) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 b0 = (__bf16)x[i];
+    const float r1 = x[i] - (float)b0;
+    const __bf16 b1 = (__bf16)r1;
+    s0[i] = b0; s1[i] = b1; s2[i] = (__bf16)(r1 - (float)b1);
+  }
+}
+
+template <bool VEC, bool RELU, bool BF16X3>
 __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __restrict__ P, int64_t ldp,
                                                                 const float* G, int64_t ldg,
                                                                 const float* __restrict__ Y, int64_t ldy,
@@ -269,16 +282,45 @@ __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __r
       fetch(mb + (t + 1) * BK);
       if (do_bias) tally();
     }
+    if constexpr (BF16X3) {
+      // the 16 node rows of the tile as ONE K = 16 step on the bf16 matrix pipe: both operands split three ways in
+      // registers (x = x0 + x1 + x2, 24 mantissa bits) and the six significant cross terms accumulated in fp32 —
+      // fp32-accurate at 3/8 of the f32 MFMA cycles (fused.hip: mfma_half_bf16x3)
+      bf16x8 as[2][3], bs3[2][3];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = Ps[buf][kk + fk][wm * 64 + fr];
-      const float a1 = Ps[buf][kk + fk][wm * 64 + 32 + fr];
-      const float b0 = Gs[buf][kk + fk][wn * 64 + fr];
-      const float b1 = Gs[buf][kk + fk][wn * 64 + 32 + fr];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          av[k] = Ps[buf][8 * fk + k][wm * 64 + i * 32 + fr];
+          bv[k] = Gs[buf][8 * fk + k][wn * 64 + i * 32 + fr];
+        }
+        split3_bf16(av, as[i][0], as[i][1], as[i][2]);
+        split3_bf16(bv, bs3[i][0], bs3[i][1], bs3[i][2]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][0], bs3[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][1], bs3[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][2], bs3[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][0], bs3[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][1], bs3[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][0], bs3[j][0], acc[i][j], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        const float a0 = Ps[buf][kk + fk][wm * 64 + fr];
+        const float a1 = Ps[buf][kk + fk][wm * 64 + 32 + fr];
+        const float b0 = Gs[buf][kk + fk][wn * 64 + fr];
+        const float b1 = Gs[buf][kk + fk][wn * 64 + 32 + fr];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
     if (t + 1 < ntiles) stash(buf ^ 1);
     __syncthreads();
@@ -460,8 +502,8 @@ static int wgrad_common(const float* P, int64_t ldp, const float* G, int64_t ldg
   }
   const dim3 grid((unsigned)(tiles * n_chunk));
 #define MP_WGRAD(VECV, RELUV)                                                                                     \
-  hipLaunchKernelGGL((dense_wgrad_kernel<VECV, RELUV>), grid, dim3(kBlock), 0, st, P, ldp, G, ldg, Y, ldy, GM, ldgm, M, \
-                     F, d, chunk, (float*)ws, bias_slabs)
+  hipLaunchKernelGGL((dense_wgrad_kernel<VECV, RELUV, true>), grid, dim3(kBlock), 0, st, P, ldp, G, ldg, Y, ldy, GM,     \
+                     ldgm, M, F, d, chunk, (float*)ws, bias_slabs)
   if (Y) { if (vec) MP_WGRAD(true, true); else MP_WGRAD(false, true); }
   else { if (vec) MP_WGRAD(true, false); else MP_WGRAD(false, false); }
 #undef MP_WGRAD
