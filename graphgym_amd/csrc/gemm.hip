@@ -26,6 +26,59 @@ constexpr int BM = 128, BK = 16, APAD = 17;
 // one wave per SIMD and measured 25 % slower — not built (profiles/r01_dense.log has the measurement).
 // VEC = operands allow 16-byte loads (F % 8 == 0, d % 4 == 0, aligned rows); otherwise the loaders fall back to
 // guarded scalar loads (any F, d, leading dimension: e.g. Cora's F = 1433) and everything else is unchanged.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// ---- fp32 products on the bf16 matrix pipe --------------------------------------------------------------------------
+// gfx950 runs f32 MFMA at 1/16 of the bf16 rate.  Every operand is split three ways, x = s0 + s1 + s2 with s0 = bf16(x),
+// s1 = bf16(x - s0), s2 = bf16(x - s0 - s1) (24 mantissa bits in all), and a product keeps the six cross terms down to
+// 2^-24 of the result (a0 b0 + a0 b1 + a1 b0 + a0 b2 + a1 b1 + a2 b0), each a v_mfma_f32_32x32x16_bf16 accumulating in
+// fp32 (a bf16 x bf16 product is exact in fp32): six bf16 MFMAs of K = 16 replace eight f32 MFMAs of K = 2 at 3/8 of the
+// cycles, fp32-accurate.  The split happens ONCE per element, in the thread that stages it into LDS (splitting in the
+// MFMA lanes instead repeats it per consuming wave and is VALU-bound: 11.5 ms instead of 13.6 for the weight gradient,
+// not the 2.7x the MFMA count promises).
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& s0, bf16x8& s1, bf16x8& s2) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 b0 = (__bf16)x[i];
+    const float r1 = x[i] - (float)b0;
+    const __bf16 b1 = (__bf16)r1;
+    s0[i] = b0; s1[i] = b1; s2[i] = (__bf16)(r1 - (float)b1);
+  }
+}
+
+// A [16 k-rows][128 columns] bf16 tile with 256-byte rows whose 16-byte chunks are XOR-swizzled so that both the
+// row-wise 16-byte stores of the loaders and the transposed reads below are free of bank conflicts
+// (cdna_hip_programming.md T10, image (b)).  One plane per split: 4 KiB.
+constexpr int kPlaneBytes = 16 * 256;
+__device__ __forceinline__ int swz_off(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+// the MFMA operand of a k-strided tile: lane l of the wave gets, for column col0 + (l & 31), the 8 k-rows 8 (l >> 5) ..
+// + 7 — two ds_read_b64_tr_b16 (hardware transpose read: per 16-lane group a 4-row x 16-column block, lane 4q + p
+// supplying the address of row q, columns 4p .. 4p + 3, lane i receiving column i).  EXEC must be all ones.
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* plane, int col0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int chunk = ((col0 + 16 * (g & 1)) >> 3) + (p >> 1);
+  const int r0 = 8 * (g >> 1) + q;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (lds_s16x4*)(plane + swz_off(r0, chunk) + 8 * (p & 1)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (lds_s16x4*)(plane + swz_off(r0 + 4, chunk) + 8 * (p & 1)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
 template <bool DUAL, int TN, bool VEC>
 __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(const float* __restrict__ P, int64_t ldp,
                                                              const float* __restrict__ W,
@@ -36,8 +89,11 @@ __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(co
                                                              int32_t F, int32_t d) {
   constexpr int BN = 64 * TN;
   constexpr int NB4 = BN / 64;           // float4 loads of B per thread per tile
-  __shared__ float As[2][BM][APAD];
-  __shared__ float Bs[2][BK][BN];
+  static_assert(TN == 2, "the bf16 LDS images below are laid out for a 128-column block tile");
+  // bf16x3 images (three split planes each): A [128 rows][16 k] k-contiguous (a lane's operand is one 16-byte read);
+  // B [16 k][128 columns] row-major, chunk-swizzled, consumed through transposed reads
+  __shared__ __attribute__((aligned(16))) unsigned char Aimg[2][3][BM * 32];
+  __shared__ __attribute__((aligned(16))) unsigned char Bimg[2][3][kPlaneBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -95,13 +151,18 @@ __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(co
     }
   };
   auto stash = [&](int buf) {
+    const float av[8] = {ra[0][0], ra[0][1], ra[0][2], ra[0][3], ra[1][0], ra[1][1], ra[1][2], ra[1][3]};
+    bf16x8 sa[3];
+    split3_bf16(av, sa[0], sa[1], sa[2]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      As[buf][a_row][a_k + i] = ra[0][i];
-      As[buf][a_row][a_k + 4 + i] = ra[1][i];
-    }
+    for (int pl = 0; pl < 3; ++pl)
+      *reinterpret_cast<bf16x8*>(&Aimg[buf][pl][a_row * 32 + (a_k >> 3) * 16]) = sa[pl];
+    const float bv[8] = {rb[0][0], rb[0][1], rb[0][2], rb[0][3], rb[1][0], rb[1][1], rb[1][2], rb[1][3]};
+    bf16x8 sb[3];
+    split3_bf16(bv, sb[0], sb[1], sb[2]);
 #pragma unroll
-    for (int q = 0; q < NB4; ++q) *reinterpret_cast<f32x4*>(&Bs[buf][b_k][b_n + 4 * q]) = rb[q];
+    for (int pl = 0; pl < 3; ++pl)
+      *reinterpret_cast<bf16x8*>(&Bimg[buf][pl][swz_off(b_k, b_n >> 3)]) = sb[pl];
   };
 
   f32x16 acc[2][TN];
@@ -120,18 +181,22 @@ __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(co
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
     if (t + 1 < ntiles) fetch((t + 1) * BK);          // in flight while the MFMAs below run
+    {
+      // the K = 16 tile as one step on the bf16 matrix pipe: operands were split when they were staged
+      bf16x8 as[2][3], bs3[TN][3];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = As[buf][wm * 64 + fr][kk + fk];
-      const float a1 = As[buf][wm * 64 + 32 + fr][kk + fk];
-      float bf[TN];
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][kk + fk][wn * (32 * TN) + j * 32 + fr];
+        for (int pl = 0; pl < 3; ++pl)
+          as[i][pl] = *reinterpret_cast<const bf16x8*>(&Aimg[buf][pl][(wm * 64 + i * 32 + fr) * 32 + fk * 16]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[j], acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[j], acc[1][j], 0, 0, 0);
-      }
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bs3[j][pl] = tr_read8(Bimg[buf][pl], wn * (32 * TN) + j * 32, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mfma6(acc[i][j], as[i], bs3[j]);
     }
     if (t + 1 < ntiles) stash(buf ^ 1);               // the other buffer: nobody reads it this iteration
     __syncthreads();
@@ -166,20 +231,7 @@ __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(co
 // RELU: the backward of a ReLU epilogue rides along — g is masked by [Y > 0] (Y = the forward output) on its way to
 // LDS, and the blocks of the first f-tile also write the masked gradient GM (what the input-gradient launch reads):
 // the separate masking pass (30 GB at 10^7 x 256) disappears into a pass that is bound by its MFMA work.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// x = s0 + s1 + s2 with s0 = bf16(x), s1 = bf16(x - s0), s2 = bf16(x - s0 - s1): 24 mantissa bits in three bf16 values
-__device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& s0, bf16x8& s1, bf16x8& s2) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 b0 = (__bf16)x[i];
-    const float r1 = x[i] - (float)b0;
-    const __bf16 b1 = (__bf16)r1;
-    s0[i] = b0; s1[i] = b1; s2[i] = (__bf16)(r1 - (float)b1);
-  }
-}
-
-template <bool VEC, bool RELU, bool BF16X3>
+template <bool VEC, bool RELU>
 __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __restrict__ P, int64_t ldp,
                                                                 const float* G, int64_t ldg,
                                                                 const float* __restrict__ Y, int64_t ldy,
@@ -188,8 +240,10 @@ __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __r
                                                                 float* __restrict__ slabs,
                                                                 float* __restrict__ bias_slabs) {
   constexpr int BT = 128;                 // output tile 128 (f) x 128 (d)
-  __shared__ float Ps[2][BK][BT];
-  __shared__ float Gs[2][BK][BT];
+  // bf16x3 images: [16 node rows][128 columns] per split plane, chunk-swizzled; both MFMA operands are k-strided
+  // (k = node row) and come out of them through transposed reads
+  __shared__ __attribute__((aligned(16))) unsigned char Pimg[2][3][kPlaneBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char Gimg[2][3][kPlaneBytes];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tf = (F + BT - 1) / BT, td = (d + BT - 1) / BT;
@@ -244,10 +298,17 @@ __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __r
     }
   };
   auto stash = [&](int buf) {
-    *reinterpret_cast<f32x4*>(&Ps[buf][l_row][l_col]) = rp[0];
-    *reinterpret_cast<f32x4*>(&Ps[buf][l_row][l_col + 4]) = rp[1];
-    *reinterpret_cast<f32x4*>(&Gs[buf][l_row][l_col]) = rg[0];
-    *reinterpret_cast<f32x4*>(&Gs[buf][l_row][l_col + 4]) = rg[1];
+    const float pv[8] = {rp[0][0], rp[0][1], rp[0][2], rp[0][3], rp[1][0], rp[1][1], rp[1][2], rp[1][3]};
+    const float gv[8] = {rg[0][0], rg[0][1], rg[0][2], rg[0][3], rg[1][0], rg[1][1], rg[1][2], rg[1][3]};
+    bf16x8 sp[3], sg[3];
+    split3_bf16(pv, sp[0], sp[1], sp[2]);
+    split3_bf16(gv, sg[0], sg[1], sg[2]);
+    const int off = swz_off(l_row, l_col >> 3);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      *reinterpret_cast<bf16x8*>(&Pimg[buf][pl][off]) = sp[pl];
+      *reinterpret_cast<bf16x8*>(&Gimg[buf][pl][off]) = sg[pl];
+    }
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -282,45 +343,20 @@ __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __r
       fetch(mb + (t + 1) * BK);
       if (do_bias) tally();
     }
-    if constexpr (BF16X3) {
-      // the 16 node rows of the tile as ONE K = 16 step on the bf16 matrix pipe: both operands split three ways in
-      // registers (x = x0 + x1 + x2, 24 mantissa bits) and the six significant cross terms accumulated in fp32 —
-      // fp32-accurate at 3/8 of the f32 MFMA cycles (fused.hip: mfma_half_bf16x3)
+    {
+      // the 16 node rows of the tile as ONE K = 16 step on the bf16 matrix pipe (operands split when staged)
       bf16x8 as[2][3], bs3[2][3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float av[8], bv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          av[k] = Ps[buf][8 * fk + k][wm * 64 + i * 32 + fr];
-          bv[k] = Gs[buf][8 * fk + k][wn * 64 + i * 32 + fr];
-        }
-        split3_bf16(av, as[i][0], as[i][1], as[i][2]);
-        split3_bf16(bv, bs3[i][0], bs3[i][1], bs3[i][2]);
-      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][0], bs3[j][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][1], bs3[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][2], bs3[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][0], bs3[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][1], bs3[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i][0], bs3[j][0], acc[i][j], 0, 0, 0);
+        for (int pl = 0; pl < 3; ++pl) {
+          as[i][pl] = tr_read8(Pimg[buf][pl], wm * 64 + i * 32, lane);
+          bs3[i][pl] = tr_read8(Gimg[buf][pl], wn * 64 + i * 32, lane);
         }
-    } else {
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        const float a0 = Ps[buf][kk + fk][wm * 64 + fr];
-        const float a1 = Ps[buf][kk + fk][wm * 64 + 32 + fr];
-        const float b0 = Gs[buf][kk + fk][wn * 64 + fr];
-        const float b1 = Gs[buf][kk + fk][wn * 64 + 32 + fr];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      }
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mfma6(acc[i][j], as[i], bs3[j]);
     }
     if (t + 1 < ntiles) stash(buf ^ 1);
     __syncthreads();
@@ -339,13 +375,14 @@ __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __r
     }
   }
   if (do_bias) {   // 16 threads hold partial sums of the same 8 columns: add them in row order through LDS
-    *reinterpret_cast<f32x4*>(&Gs[0][l_row][l_col]) = f32x4{bs[0], bs[1], bs[2], bs[3]};
-    *reinterpret_cast<f32x4*>(&Gs[0][l_row][l_col + 4]) = f32x4{bs[4], bs[5], bs[6], bs[7]};
+    float (*red)[BT] = reinterpret_cast<float (*)[BT]>(&Pimg[0][0][0]);      // [16][128] floats = 8 KiB of the 24 KiB image
+    *reinterpret_cast<f32x4*>(&red[l_row][l_col]) = f32x4{bs[0], bs[1], bs[2], bs[3]};
+    *reinterpret_cast<f32x4*>(&red[l_row][l_col + 4]) = f32x4{bs[4], bs[5], bs[6], bs[7]};
     __syncthreads();
     if (tid < BT && d0 + tid < d) {
       float sacc = 0.f;
 #pragma unroll
-      for (int r = 0; r < BK; ++r) sacc += Gs[0][r][tid];
+      for (int r = 0; r < BK; ++r) sacc += red[r][tid];
       bias_slabs[c * (int64_t)d + d0 + tid] = sacc;
     }
   }
@@ -502,7 +539,7 @@ static int wgrad_common(const float* P, int64_t ldp, const float* G, int64_t ldg
   }
   const dim3 grid((unsigned)(tiles * n_chunk));
 #define MP_WGRAD(VECV, RELUV)                                                                                     \
-  hipLaunchKernelGGL((dense_wgrad_kernel<VECV, RELUV, true>), grid, dim3(kBlock), 0, st, P, ldp, G, ldg, Y, ldy, GM,     \
+  hipLaunchKernelGGL((dense_wgrad_kernel<VECV, RELUV>), grid, dim3(kBlock), 0, st, P, ldp, G, ldg, Y, ldy, GM,     \
                      ldgm, M, F, d, chunk, (float*)ws, bias_slabs)
   if (Y) { if (vec) MP_WGRAD(true, true); else MP_WGRAD(false, true); }
   else { if (vec) MP_WGRAD(true, false); else MP_WGRAD(false, false); }
