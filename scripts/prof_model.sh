@@ -8,5 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -- python3 $REPO/scripts/model_profile.py > $OUT/log.txt 2>&1 || { tail -5 $OUT/log.txt; exit 1; }
 find $OUT/t -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/stats.csv
+# the time-ordered launches of the first 400 ms after the graph build, to tell first-call effects from steady state
+find $OUT/t -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 $REPO/scripts/trace_head.py {} > $OUT/first_launches.txt
 find $OUT/t -type f -delete
 tail -2 $OUT/log.txt
