@@ -4,50 +4,30 @@
 // with P = A_hat X and Q = A_hat S X from the two-branch aggregation, this one kernel replaces two
 // GEMMs, an add, a bias add and an activation (five passes over [N, d]) of the library path.
 //
-// fp32 in, fp32 accumulate on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, the
-// only f32 MFMA rate gfx950 has: 64 FLOP/clk/SIMD).  The two products are one GEMM over the
-// concatenated K axis [P | Q] x [W ; W_id].
-//   block 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 2 x 2 MFMA tiles,
-//   K step 16, LDS double-buffered (A tile k-padded to 17 words: conflict-free 32-lane fragment reads),
-//   global -> register prefetch of tile t+1 issued before the MFMAs of tile t, written to LDS after.
-// 34 KiB LDS and ~110 VGPRs per block => 4 blocks (16 waves) per CU.
+// fp32 in, fp32 out, the product on the bf16 matrix pipe with three-way split operands (bf16x3.h: fp32-accurate).
+// The two products are one GEMM over the concatenated K axis [P | Q] x [W ; W_id].
+//   block 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 2 x 2 MFMA tiles, K step 16,
+//   LDS double-buffered bf16 images (operands split once, by the thread that stages them), global -> register
+//   prefetch of tile t+1 issued before the MFMAs of tile t, written to LDS after.  48 KiB LDS, 3 blocks per CU.
+// This is the general kernel (any F, d, leading dimension, the dual product).  The hot shape — one product, d = 64 /
+// 128 / 256, F % 32 == 0 — has its own streaming kernel in dense_x3.hip.
 #include "common.h"
 #include "vecio.h"
+#include "bf16x3.h"
 #include <limits.h>
 
 namespace mp {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128, BK = 16, APAD = 17;
+constexpr int BM = 128, BK = 16;
 
 // TN = 32-column MFMA tiles per wave along N: block tile 128 x (64 * TN).  TN = 2 (128 columns, 3 waves per
 // SIMD) is the default; TN = 4 (256 columns: every A row read once at d <= 256) needs 297 registers, runs
 // one wave per SIMD and measured 25 % slower — not built (profiles/r01_dense.log has the measurement).
 // VEC = operands allow 16-byte loads (F % 8 == 0, d % 4 == 0, aligned rows); otherwise the loaders fall back to
 // guarded scalar loads (any F, d, leading dimension: e.g. Cora's F = 1433) and everything else is unchanged.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-// ---- fp32 products on the bf16 matrix pipe --------------------------------------------------------------------------
-// gfx950 runs f32 MFMA at 1/16 of the bf16 rate.  Every operand is split three ways, x = s0 + s1 + s2 with s0 = bf16(x),
-// s1 = bf16(x - s0), s2 = bf16(x - s0 - s1) (24 mantissa bits in all), and a product keeps the six cross terms down to
-// 2^-24 of the result (a0 b0 + a0 b1 + a1 b0 + a0 b2 + a1 b1 + a2 b0), each a v_mfma_f32_32x32x16_bf16 accumulating in
-// fp32 (a bf16 x bf16 product is exact in fp32): six bf16 MFMAs of K = 16 replace eight f32 MFMAs of K = 2 at 3/8 of the
-// cycles, fp32-accurate.  The split happens ONCE per element, in the thread that stages it into LDS (splitting in the
-// MFMA lanes instead repeats it per consuming wave and is VALU-bound: 11.5 ms instead of 13.6 for the weight gradient,
-// not the 2.7x the MFMA count promises).
-__device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& s0, bf16x8& s1, bf16x8& s2) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 b0 = (__bf16)x[i];
-    const float r1 = x[i] - (float)b0;
-    const __bf16 b1 = (__bf16)r1;
-    s0[i] = b0; s1[i] = b1; s2[i] = (__bf16)(r1 - (float)b1);
-  }
-}
-
+// The split happens ONCE per element, in the thread that stages it into LDS (splitting in the MFMA lanes instead repeats
+// it per consuming wave and is VALU-bound here: 11.5 ms instead of 13.6 for the weight gradient, not the 2.7x the MFMA
+// count promises); bf16x3.h has the split and the six-term product.
 // A [16 k-rows][128 columns] bf16 tile with 256-byte rows whose 16-byte chunks are XOR-swizzled so that both the
 // row-wise 16-byte stores of the loaders and the transposed reads below are free of bank conflicts
 // (cdna_hip_programming.md T10, image (b)).  One plane per split: 4 KiB.
@@ -70,15 +50,6 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* plane, int col0,
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
-__device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
-}
-
 template <bool DUAL, int TN, bool VEC>
 __global__ __launch_bounds__(kBlock, TN == 2 ? 3 : 1) void dense_fused_kernel(const float* __restrict__ P, int64_t ldp,
                                                              const float* __restrict__ W,

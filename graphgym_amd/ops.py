@@ -87,6 +87,8 @@ def _raw_dense_fused(P, W, Q, W_id, bias, relu):
     L = lib()
     M, F = P.shape
     d = W.size(1)
+    if Q is None and dense_x3_supported(P, F, d):
+        return _raw_dense_x3(P, W, bias, relu)
     out = placement.empty_or_torch((M, d), P.device, reads=(P, Q))
     Wc = W.contiguous()
     Wi = None if W_id is None else W_id.contiguous()
@@ -99,6 +101,58 @@ def _raw_dense_fused(P, W, Q, W_id, bias, relu):
         return None
     check(st, "mp_dense_fused_f32")
     return out
+
+
+X3_WIDTHS = (64, 128, 256)
+X3_MIN_ROWS = int(os.environ.get("MP_X3_MIN_ROWS", 1 << 17))   # below this the persistent 256-row blocks do not fill the chip
+
+
+def _split_w(W, trans=False):
+    """W -> the engine's three-way bf16 split of W (or of W^T): [3, K / 8, n, 8] bf16 (mp_split_w_bf16x3; one
+    small launch, so nothing is cached across calls)"""
+    Wc = W.detach()
+    if Wc.stride(1) != 1 and Wc.stride(0) == 1:      # a transposed view (nn.Linear's weight.t()): split its base
+        Wc, trans = Wc.t(), not trans
+    elif Wc.stride(1) != 1:
+        Wc = Wc.contiguous()
+    K, n = (Wc.size(1), Wc.size(0)) if trans else (Wc.size(0), Wc.size(1))
+    sp = torch.empty((3, K // 8, n, 8), dtype=torch.bfloat16, device=Wc.device)
+    with torch.cuda.device(Wc.device):
+        check(lib().mp_split_w_bf16x3(ptr(Wc), Wc.stride(0), K, n, 1 if trans else 0, ptr(sp), _stream()),
+              "mp_split_w_bf16x3")
+    return sp
+
+
+def dense_x3_supported(P, K, n, out=None):
+    """shapes the streaming transform takes (mp_dense_x3_f32): [M, K] @ [K, n] with n = 64 / 128 / 256, K % 32 == 0,
+    K >= 64, 16-byte-aligned rows on both sides, and enough rows to fill the chip; MP_X3=0 turns it off (A/B timing)"""
+    return (os.environ.get("MP_X3", "1") != "0" and P.dim() == 2 and P.size(0) >= X3_MIN_ROWS and n in X3_WIDTHS
+            and K % 32 == 0 and K >= 64 and P.size(1) == K and P.stride(1) == 1 and P.stride(0) % 4 == 0
+            and P.data_ptr() % 16 == 0 and P.dtype == torch.float32
+            and (out is None or (out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0)))
+
+
+def _raw_dense_x3(P, W, bias=None, relu=False, trans=False, out=None):
+    """act(P @ W + bias) (trans: P @ W^T) on the streaming kernel; the caller has checked dense_x3_supported"""
+    M, K = P.shape
+    n = W.size(0) if trans else W.size(1)
+    sp = _split_w(W, trans)
+    if out is None:
+        out = placement.empty_or_torch((M, n), P.device, reads=(P,))
+    b = None if bias is None else bias.detach().contiguous()
+    if b is not None and b.data_ptr() % 16:
+        b = b.clone()                        # a slice of a longer bias: the kernel reads it in 16-byte groups
+    with torch.cuda.device(P.device):
+        check(lib().mp_dense_x3_f32(ptr(P), P.stride(0), ptr(sp), ptr(b), _lib.ACT_RELU if relu else _lib.ACT_NONE,
+                                    ptr(out), out.stride(0), M, K, n, _stream()), "mp_dense_x3_f32")
+    return out
+
+
+def times_wt(g, W):
+    """g @ W^T — the input gradient of a transform: the streaming kernel at its shapes, else the library GEMM"""
+    if dense_x3_supported(g, W.size(1), W.size(0)):
+        return _raw_dense_x3(g, W, trans=True)
+    return torch.mm(g, W.detach().t())
 
 
 FUSED_WIDTHS = (64, 128, 256, 512)
@@ -225,6 +279,9 @@ def _dense_into(out_view, P, W, bias, relu):
     L = lib()
     M, F = P.shape
     d = W.size(1)
+    if dense_x3_supported(P, F, d, out_view):
+        _raw_dense_x3(P, W, bias, relu, out=out_view)
+        return
     Wc = W.contiguous()
     b = None if bias is None else bias.contiguous()
     with torch.cuda.device(P.device):
@@ -256,9 +313,6 @@ class _ConcatDense(torch.autograd.Function):
             g = torch.ops.aten.threshold_backward(g, out, 0.0)
         g = g.contiguous()
         gs, gn = g[:, :ku], g[:, ku:]                      # strided views: the kernels take leading dimensions
-
-        def times_wt(gv, Wm):   # plain product -> library GEMM
-            return torch.mm(gv, Wm.detach().t())
 
         dx = times_wt(gs, Ws) if ctx.needs_input_grad[0] else None
         dm = times_wt(gn, Wn) if ctx.needs_input_grad[1] else None
@@ -304,7 +358,7 @@ class _SageConcatFused(torch.autograd.Function):
         db = torch.cat([dbs, dbn]) if ctx.has_bias else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(gs, Ws.detach().t())          # plain product -> library GEMM
+            dx = times_wt(gs, Ws)
             gt = ctx.g.transpose_mean()
             Wnt = Wn.detach().t().contiguous()
             if agg_dense_supported(gt, gn, Wnt):
@@ -786,9 +840,9 @@ def _dense_any(P, W, Q, W_id, bias, relu):
     Pc = _f32c(P, "P")
     Qc = None if Q is None else _f32c(Q, "Q")
     out = None
-    if Qc is None and bias is None and not relu:
-        # a plain product has nothing to fuse: the library GEMM (scripts/gemm_layouts.py: 9.9 vs 11.8 ms at
-        # 10^7 x 256 x 256); the engine's kernel earns its keep when bias / activation / a second product ride along
+    if Qc is None and bias is None and not relu and not dense_x3_supported(Pc, Pc.size(1), W.size(1)):
+        # a plain product outside the streaming kernel's shapes has nothing to fuse: the library GEMM; the general
+        # MFMA kernel earns its keep when bias / activation / a second product ride along
         return torch.mm(Pc, W)
     out = _raw_dense_fused(Pc, W, Qc, W_id, bias, relu)
     if out is None:     # shape outside the fused kernel: library GEMMs
@@ -972,10 +1026,10 @@ def _dense_backward(ctx, g):
     P, W, Q, W_id, out = ctx.saved_tensors
     need = ctx.needs_input_grad
     # the weight and bias gradients come out of one pass of the engine's split-K kernel, which also applies the ReLU
-    # mask to g on the way; g @ W^T is a plain product -> library GEMM (9.8 vs 11.8 ms at 10^7 x 256 x 256)
+    # mask to g on the way; g @ W^T is the streaming transform with W^T (library GEMM outside its shapes)
     g, dW, db = _masked_grads(P, g, out, ctx.relu, need[1], ctx.has_bias and need[4])
-    dP = torch.mm(g, W.t()) if need[0] else None
-    dQ = torch.mm(g, W_id.t()) if (ctx.has_q and need[2]) else None
+    dP = times_wt(g, W) if need[0] else None
+    dQ = times_wt(g, W_id) if (ctx.has_q and need[2]) else None
     dWid = torch.ops.mp.dense_wgrad_raw(Q, g, True, False)[0] if (ctx.has_q and need[3]) else None
     return dP, dW, dQ, dWid, db, None
 

@@ -157,8 +157,10 @@ class Arena:
         if np.all(np.isnan(T)):
             return np.zeros(n)
         tmin = np.nanmin(T)
-        row = np.nanmean(T / tmin - 1.0, axis=0)
-        row[np.isnan(row)] = np.nanmax(row)          # granules without a free chunk: priced as the worst
+        have = ~np.all(np.isnan(T), axis=0)
+        row = np.full(n, np.nan)
+        row[have] = np.nanmean(T[:, have] / tmin - 1.0, axis=0)
+        row[~have] = np.nanmax(row)                  # granules without a free chunk: priced as the worst
         return row
 
     # ---- allocation ---------------------------------------------------------------------

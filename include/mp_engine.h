@@ -333,6 +333,22 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W,
                        const float* bias, int act, float* out, int64_t ldo,
                        int64_t M, int32_t F, int32_t d, mp_stream_t stream);
 
+/* The same transform at its hot shape, as a streaming kernel (dense_x3.hip): out = act(P @ W + bias) with
+ * d = 64 / 128 / 256, F % 32 == 0 and F >= 64 (MP_ERR_UNSUPPORTED otherwise: use mp_dense_fused_f32), P and out 16-byte
+ * aligned with ldp % 4 == 0 and ldo % 4 == 0 (MP_ERR_ALIGNMENT).  The Linear / kernel product of every layer (x @ kernel, TfgIDLayer.py:510-523;
+ * GeneralLayer's Linear, layer.py:136-147; the GIN MLPs, idconv.py:371-399) and, with W_split made from W^T, the
+ * input gradient of that product.  W_split = W three-way split into bf16 by mp_split_w_bf16x3 (the layout
+ * mp_agg_dense_f32 takes); the product runs on the bf16 matrix pipe with all six significant cross terms
+ * (fp32-accurate), P staged by LDS-DMA and read from HBM once. */
+int mp_dense_x3_f32(const float* P, int64_t ldp, const void* W_split, const float* bias, int32_t act, float* out,
+                    int64_t ldo, int64_t M, int32_t F, int32_t d, mp_stream_t stream);
+
+/* W_split [3][K / 8][n][8] bf16 (6 K n bytes, 16-byte aligned) from fp32 weights: element [s][k / 8][c][k % 8] =
+ * plane s of B[k][c], plane s = bf16(B - sum of the planes before it).  trans == 0: B = W, W [K, n] with leading
+ * dimension ldw; trans != 0: B = W^T, W [n, K].  K % 8 == 0. */
+int mp_split_w_bf16x3(const float* W, int64_t ldw, int32_t K, int32_t n, int32_t trans, void* W_split,
+                      mp_stream_t stream);
+
 /* weight gradient of the transform: dW [F, d] = P^T @ G with P [M, F], G [M, d] (backward of K11 under
  * loss.backward(), graphgym/train.py:24).  Split over the node axis into slabs in `ws`
  * (mp_dense_wgrad_ws_bytes), summed in a fixed order: bitwise reproducible.  Any F, d.
