@@ -238,7 +238,7 @@ def _raw_dense_wgrad(P, G, want_bias=False):
     return (out, db) if want_bias else out
 
 
-def _raw_dense_wgrad_relu(P, G, Y, want_bias=False):
+def _raw_dense_wgrad_relu(P, G, Y, want_bias=False, want_gm=True):
     """(P^T (G * [Y > 0]), its column sums or None, G * [Y > 0]) in one pass (mp_dense_wgrad_relu_f32): the weight-gradient
     kernel masks the incoming gradient by the forward's ReLU pattern as it reads it and writes the masked gradient out
     for the input-gradient launch; None when the shape is outside the kernel"""
@@ -247,13 +247,15 @@ def _raw_dense_wgrad_relu(P, G, Y, want_bias=False):
     d = G.size(1)
     out = torch.empty((F, d), dtype=torch.float32, device=P.device)
     db = torch.empty(d, dtype=torch.float32, device=P.device) if want_bias else None
-    gm = placement.empty_or_torch((M, d), P.device, reads=(G, Y, P))
+    # the masked gradient is written only when an input-gradient launch will read it (a first layer has none)
+    gm = placement.empty_or_torch((M, d), P.device, reads=(G, Y, P)) if want_gm else None
     with torch.cuda.device(P.device):
         nb = C.c_size_t(0)
         check(L.mp_dense_wgrad_ws_bytes(M, F, d, C.byref(nb)))
         ws = torch.empty(max(nb.value, 1), dtype=torch.uint8, device=P.device)
         st = L.mp_dense_wgrad_relu_f32(ptr(P), P.stride(0), ptr(G), G.stride(0), ptr(Y), Y.stride(0), ptr(gm),
-                                       gm.stride(0), M, F, d, ptr(out), ptr(db), ptr(ws), nb.value, _stream())
+                                       gm.stride(0) if gm is not None else 0, M, F, d, ptr(out), ptr(db), ptr(ws),
+                                       nb.value, _stream())
     if st in (2, 5):
         return None
     check(st, "mp_dense_wgrad_relu_f32")
@@ -881,31 +883,35 @@ def _(X, G, want_w, want_b):
 
 
 @custom_op("mp::dense_wgrad_relu_raw", mutates_args=(), device_types="cuda")
-def _op_dense_wgrad_relu_raw(X: Tensor, G: Tensor, Y: Tensor, want_b: bool) -> Tuple[Tensor, Tensor, Tensor]:
-    """(X^T gm, column sums of gm, gm) with gm = G * [Y > 0]: the ReLU backward folded into the weight-gradient pass"""
+def _op_dense_wgrad_relu_raw(X: Tensor, G: Tensor, Y: Tensor, want_b: bool,
+                             want_gm: bool = True) -> Tuple[Tensor, Tensor, Tensor]:
+    """(X^T gm, column sums of gm, gm) with gm = G * [Y > 0]: the ReLU backward folded into the weight-gradient pass;
+    want_gm False: gm is not written (nobody reads it) and comes back empty"""
     Gc = G if (G.stride(-1) == 1 and G.dim() == 2) else G.contiguous()
     Yc = Y if Y.stride(-1) == 1 else Y.contiguous()
     Xc = X if X.stride(-1) == 1 else X.contiguous()
-    r = _raw_dense_wgrad_relu(Xc, Gc, Yc, want_bias=want_b)
+    r = _raw_dense_wgrad_relu(Xc, Gc, Yc, want_bias=want_b, want_gm=want_gm)
     if r is None:     # shape outside the kernel: separate passes
         gm = torch.ops.aten.threshold_backward(Gc, Yc, 0.0)
         dW, db = _wgrad_and_bias(Xc, gm, True, want_b)
-        return dW, (db if db is not None else _empty_like_none(G)), gm
+        return dW, (db if db is not None else _empty_like_none(G)), (gm if want_gm else _empty_like_none(G))
     dW, db, gm = r
-    return dW, (db if db is not None else _empty_like_none(G)), gm
+    return dW, (db if db is not None else _empty_like_none(G)), (gm if gm is not None else _empty_like_none(G))
 
 
 @_op_dense_wgrad_relu_raw.register_fake
-def _(X, G, Y, want_b):
-    return (G.new_empty((X.size(1), G.size(1))), G.new_empty((G.size(1),) if want_b else (0,)), G.new_empty(G.shape))
+def _(X, G, Y, want_b, want_gm=True):
+    return (G.new_empty((X.size(1), G.size(1))), G.new_empty((G.size(1),) if want_b else (0,)),
+            G.new_empty(G.shape if want_gm else (0,)))
 
 
-def _masked_grads(P, gout, out, relu, need_w, need_b):
+def _masked_grads(P, gout, out, relu, need_w, need_b, need_gm=True):
     """(gm, dW, db) for a transform with an optional ReLU epilogue: with ReLU and a weight gradient wanted the mask rides
-    in the weight-gradient pass (one kernel); otherwise threshold_backward / plain weight gradient"""
+    in the weight-gradient pass (one kernel); otherwise threshold_backward / plain weight gradient.  need_gm False
+    (no input gradient will be taken): gm may come back None and is not written."""
     if relu and need_w and P is not None and P.numel() > 0:
-        dW, db, gm = torch.ops.mp.dense_wgrad_relu_raw(P, gout, out, need_b)
-        return gm, dW, _none_if_empty(db)
+        dW, db, gm = torch.ops.mp.dense_wgrad_relu_raw(P, gout, out, need_b, need_gm)
+        return (gm if need_gm else None), dW, _none_if_empty(db)
     gm = gout.contiguous()
     if relu:
         gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
@@ -1027,7 +1033,8 @@ def _dense_backward(ctx, g):
     need = ctx.needs_input_grad
     # the weight and bias gradients come out of one pass of the engine's split-K kernel, which also applies the ReLU
     # mask to g on the way; g @ W^T is the streaming transform with W^T (library GEMM outside its shapes)
-    g, dW, db = _masked_grads(P, g, out, ctx.relu, need[1], ctx.has_bias and need[4])
+    need_gm = need[0] or (ctx.has_q and (need[2] or need[3]))
+    g, dW, db = _masked_grads(P, g, out, ctx.relu, need[1], ctx.has_bias and need[4], need_gm)
     dP = times_wt(g, W) if need[0] else None
     dQ = times_wt(g, W_id) if (ctx.has_q and need[2]) else None
     dWid = torch.ops.mp.dense_wgrad_raw(Q, g, True, False)[0] if (ctx.has_q and need[3]) else None
@@ -1070,7 +1077,7 @@ def _agg_dense_backward(ctx, gout, _gP):
     if not ctx.want_P and (need[1]):   # the aggregated rows were not kept (called outside grad mode bookkeeping)
         P = torch.ops.mp.spmm_raw(x, ctx.graph, 0, ctx.reduce, x if ctx.self_scale != 0.0 else None, ctx.self_scale,
                                   None, False, False)[0]
-    gm, dW, db = _masked_grads(P, gout, out, ctx.relu, need[1], ctx.has_bias and need[2])
+    gm, dW, db = _masked_grads(P, gout, out, ctx.relu, need[1], ctx.has_bias and need[2], need[0])
     dx = None
     if need[0]:
         # dx = (A^T g + s g) W^T: the same one-kernel layer on the transposed operator (mean: entries w / count)
@@ -1121,7 +1128,7 @@ def _agg_dense_id_backward(ctx, gout, _gP, _gxid):
     if not ctx.want_P and need[1]:
         P = torch.ops.mp.spmm_raw(x, ctx.graph, 0, _lib.SUM, x if ctx.self_scale != 0.0 else None, ctx.self_scale,
                                   None, False, False)[0]
-    gm, dW, db = _masked_grads(P, gout, out, ctx.relu, need[1], ctx.has_bias and need[3])
+    gm, dW, db = _masked_grads(P, gout, out, ctx.relu, need[1], ctx.has_bias and need[3], need[0] or need[2])
     # identity branch: T = A_id^T g [n_id, d_out];  dW_id = x_id^T T ;  dx[id] += T W_id^T
     T = torch.ops.mp.id_branch_t_raw(gm, ctx.graph, id_index) if (need[0] or need[2]) else None
     dWid = torch.mm(x_id.t(), T) if need[2] else None

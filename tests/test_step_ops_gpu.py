@@ -39,6 +39,11 @@ def test_wgrad_with_relu_mask(dev, M, Fi, d):
     check(L.mp_dense_wgrad_relu_f32(ptr(Pd), Fi, ptr(G2), d, ptr(Yd), d, ptr(G2), d, M, Fi, d, ptr(dW2), None, ptr(ws),
                                     nb.value, _stream()))
     assert torch.equal(G2.cpu(), ref_gm) and torch.equal(dW2, dW)
+    # a first layer takes no input gradient: the masked gradient is not written at all, the sums are the same bits
+    dW3, db3, gm3 = ops._raw_dense_wgrad_relu(P.to(dev), G.to(dev), Y.to(dev), want_bias=True, want_gm=False)
+    assert gm3 is None and torch.equal(dW3, dW) and torch.equal(db3, db)
+    dW4, db4, gm4 = torch.ops.mp.dense_wgrad_relu_raw(P.to(dev), G.to(dev), Y.to(dev), True, False)
+    assert gm4.numel() == 0 and torch.equal(dW4, dW)
 
 
 def test_relu_layers_backward_has_no_separate_mask_pass(dev):
