@@ -359,6 +359,156 @@ __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __r
   }
 }
 
+// The same product with a 256 (f) x 128 (d) output tile per block (F > 128): wave w owns f rows 64 w .. 64 w + 63 and
+// all four 32-column d tiles (128 accumulator registers), so a staged element of g feeds eight MFMA tiles instead of
+// four and g, y and the masked-gradient output pass through a block ONCE per d tile instead of once per (f, d) tile
+// pair.  The kernel is bound by the issue of its vector memory instructions (section on dense_x3.hip in DESIGN.md):
+// per MFMA this form issues 40 % fewer with the ReLU mask, 25 % fewer without.  72 KiB LDS: two blocks per CU.
+template <bool RELU>
+__global__ __launch_bounds__(kBlock, 2) void dense_wgrad_wide_kernel(const float* __restrict__ P, int64_t ldp,
+                                                                     const float* G, int64_t ldg,
+                                                                     const float* __restrict__ Y, int64_t ldy,
+                                                                     float* GM, int64_t ldgm,
+                                                                     int64_t M, int32_t F, int32_t d, int64_t chunk,
+                                                                     float* __restrict__ slabs,
+                                                                     float* __restrict__ bias_slabs) {
+  constexpr int BF = 256, BD = 128;
+  __shared__ __attribute__((aligned(16))) unsigned char Pimg[2][3][2][kPlaneBytes];   // two 128-column halves
+  __shared__ __attribute__((aligned(16))) unsigned char Gimg[2][3][kPlaneBytes];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tf = (F + BF - 1) / BF, td = (d + BD - 1) / BD;
+  const int tile = blockIdx.x % (tf * td);
+  const int64_t c = blockIdx.x / (tf * td);
+  const int f0 = (tile / td) * BF, d0 = (tile % td) * BD;
+  const int64_t mb = c * chunk;
+  const int64_t me = mb + chunk < M ? mb + chunk : M;
+
+  const int l_row = tid >> 4;              // 0..15: node row inside the tile
+  const int l_col = (tid & 15) * 8;        // 8 consecutive columns (of each 128-column half for P)
+  f32x4 rp[2][2], rg[2];
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int64_t m0) {
+    const int64_t m = m0 + l_row;
+    const bool ok = m < me;
+    const float* gs = G + m * ldg + d0 + l_col;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int fc = f0 + 128 * h + l_col;
+      const float* ps = P + m * ldp + fc;
+      rp[h][0] = (ok && fc < F) ? *reinterpret_cast<const f32x4*>(ps) : z;
+      rp[h][1] = (ok && fc + 4 < F) ? *reinterpret_cast<const f32x4*>(ps + 4) : z;
+    }
+    rg[0] = (ok && d0 + l_col < d) ? *reinterpret_cast<const f32x4*>(gs) : z;
+    rg[1] = (ok && d0 + l_col + 4 < d) ? *reinterpret_cast<const f32x4*>(gs + 4) : z;
+    if constexpr (RELU) {
+      const float* ys = Y + m * ldy + d0 + l_col;
+      const f32x4 y0 = (ok && d0 + l_col < d) ? *reinterpret_cast<const f32x4*>(ys) : z;
+      const f32x4 y1 = (ok && d0 + l_col + 4 < d) ? *reinterpret_cast<const f32x4*>(ys + 4) : z;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rg[0][i] = y0[i] > 0.f ? rg[0][i] : 0.f;
+        rg[1][i] = y1[i] > 0.f ? rg[1][i] : 0.f;
+      }
+      if (GM != nullptr && f0 == 0 && ok) {
+        float* go = GM + m * ldgm + d0 + l_col;
+        if (d0 + l_col < d) *reinterpret_cast<f32x4*>(go) = rg[0];
+        if (d0 + l_col + 4 < d) *reinterpret_cast<f32x4*>(go + 4) = rg[1];
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    const int off = swz_off(l_row, l_col >> 3);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float pv[8] = {rp[h][0][0], rp[h][0][1], rp[h][0][2], rp[h][0][3], rp[h][1][0], rp[h][1][1], rp[h][1][2],
+                           rp[h][1][3]};
+      bf16x8 sp[3];
+      split3_bf16(pv, sp[0], sp[1], sp[2]);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(&Pimg[buf][pl][h][off]) = sp[pl];
+    }
+    const float gv[8] = {rg[0][0], rg[0][1], rg[0][2], rg[0][3], rg[1][0], rg[1][1], rg[1][2], rg[1][3]};
+    bf16x8 sg[3];
+    split3_bf16(gv, sg[0], sg[1], sg[2]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(&Gimg[buf][pl][off]) = sg[pl];
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bool do_bias = bias_slabs != nullptr && f0 == 0;
+  float bs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bs[i] = 0.f;
+  auto tally = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bs[i] += rg[0][i]; bs[4 + i] += rg[1][i]; }
+  };
+
+  const int fr = lane & 31, fk = lane >> 5;
+  const int64_t ntiles = (me - mb + BK - 1) / BK;
+  if (ntiles > 0) {
+    fetch(mb);
+    if (do_bias) tally();
+    stash(0);
+  }
+  __syncthreads();
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < ntiles) {
+      fetch(mb + (t + 1) * BK);
+      if (do_bias) tally();
+    }
+    {
+      bf16x8 as[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) as[i][pl] = tr_read8(Pimg[buf][pl][wave >> 1], (wave & 1) * 64 + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x8 b3[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b3[pl] = tr_read8(Gimg[buf][pl], j * 32, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) mfma6(acc[i][j], as[i], b3);
+      }
+    }
+    if (t + 1 < ntiles) stash(buf ^ 1);
+    __syncthreads();
+  }
+  float* slab = slabs + c * (int64_t)F * d;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = d0 + j * 32 + fr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = f0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (row < F && col < d) slab[(int64_t)row * d + col] = acc[i][j][r];
+      }
+    }
+  }
+  if (do_bias) {   // 16 threads hold partial sums of the same 8 columns: add them in row order through LDS
+    float (*red)[BD] = reinterpret_cast<float (*)[BD]>(&Pimg[0][0][0][0]);
+    *reinterpret_cast<f32x4*>(&red[l_row][l_col]) = f32x4{bs[0], bs[1], bs[2], bs[3]};
+    *reinterpret_cast<f32x4*>(&red[l_row][l_col + 4]) = f32x4{bs[4], bs[5], bs[6], bs[7]};
+    __syncthreads();
+    if (tid < BD && d0 + tid < d) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int r = 0; r < BK; ++r) sacc += red[r][tid];
+      bias_slabs[c * (int64_t)d + d0 + tid] = sacc;
+    }
+  }
+}
+
 // Narrow inputs (F <= 8: the reference's synthetic datasets carry node_feature = [1.], so the first layer of every
 // model has F = 1): dW[f, :] = sum_m P[m, f] g[m, :] is a handful of weighted column sums — HBM-bound, no use for
 // 128 x 128 MFMA tiles (17.9 ms at 10^7 x 1 x 256 through them).  A thread owns one output column over a chunk of
@@ -602,6 +752,27 @@ static int wgrad_common(const float* P, int64_t ldp, const float* G, int64_t ldg
                          d, chunk, (float*)ws, bias_slabs);
     else
       hipLaunchKernelGGL(narrow_wgrad_kernel<false>, ngrid, dim3(kBlock), 0, st, P, ldp, G, ldg, Y, ldy, GM, ldgm, M,
+                         F, d, chunk, (float*)ws, bias_slabs);
+    MP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)F * d * 16)), dim3(kBlock), 0, st, (const float*)ws,
+                       n_chunk, (int64_t)F * d, dW);
+    MP_LAUNCH_CHECK();
+    if (dbias) {
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)d * 16)), dim3(kBlock), 0, st,
+                         (const float*)bias_slabs, n_chunk, (int64_t)d, dbias);
+      MP_LAUNCH_CHECK();
+    }
+    return MP_OK;
+  }
+  if (vec && F > 128) {   // the 256 x 128 tile
+    const int64_t wtiles = ceil_div(F, 256) * ceil_div(d, 128);
+    if (wtiles * n_chunk >= INT32_MAX) return MP_ERR_UNSUPPORTED;
+    const dim3 wgrid((unsigned)(wtiles * n_chunk));
+    if (Y)
+      hipLaunchKernelGGL(dense_wgrad_wide_kernel<true>, wgrid, dim3(kBlock), 0, st, P, ldp, G, ldg, Y, ldy, GM, ldgm, M,
+                         F, d, chunk, (float*)ws, bias_slabs);
+    else
+      hipLaunchKernelGGL(dense_wgrad_wide_kernel<false>, wgrid, dim3(kBlock), 0, st, P, ldp, G, ldg, Y, ldy, GM, ldgm, M,
                          F, d, chunk, (float*)ws, bias_slabs);
     MP_LAUNCH_CHECK();
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)F * d * 16)), dim3(kBlock), 0, st, (const float*)ws,
