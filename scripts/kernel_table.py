@@ -84,7 +84,16 @@ del sc
 W = torch.randn(d, d, device=dev) * 0.05
 b = torch.randn(d, device=dev)
 t = timeit(lambda: ops._dense_into(y, x, W, b, True))
-rec("dense_fused (P W + b, ReLU)", t, tflop=2.0 * n * d * d / 1e12)
+rec("dense_x3: relu(P W + b), the streaming transform (LDS-DMA staged, bf16x3)", t, 2.0 * n * d * 4 / 1e9,
+    tflop=2.0 * n * d * d / 1e12, note="reads P and writes out once; 6 bf16 MFMAs per fp32 product term")
+t = timeit(lambda: ops.times_wt(x, W))
+rec("dense_x3 with W^T: the input gradient g W^T", t, 2.0 * n * d * 4 / 1e9, tflop=2.0 * n * d * d / 1e12)
+os.environ["MP_X3"] = "0"
+t = timeit(lambda: ops._dense_into(y, x, W, b, True))
+os.environ["MP_X3"] = "1"
+rec("dense_fused, the general kernel (any shape, dual product)", t, tflop=2.0 * n * d * d / 1e12)
+t = timeit(lambda: torch.mm(x, W, out=y))
+rec("library fp32 GEMM (torch.mm) for comparison", t, tflop=2.0 * n * d * d / 1e12)
 t = timeit(lambda: ops._raw_dense_wgrad(x, y, want_bias=True))
 rec("dense_wgrad (+ bias gradient)", t, tflop=2.0 * n * d * d / 1e12)
 t = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True, out=y))
@@ -109,6 +118,10 @@ def mask_then_wgrad():
     return ops._raw_dense_wgrad(x, gm, want_bias=True)
 t = timeit(lambda: ops._raw_dense_wgrad_relu(x, x, yr, want_bias=True))
 rec("dense_wgrad with the ReLU mask folded in (+ masked gradient out)", t, tflop=2.0 * n * d * d / 1e12)
+x1 = torch.ones(n, 1, device=dev)
+t = timeit(lambda: ops._raw_dense_wgrad_relu(x1, x, yr, want_bias=True, want_gm=False))
+rec("first-layer weight gradient (F = 1) with the ReLU mask, no masked-gradient output", t, 2.0 * n * d * 4 / 1e9)
+del x1
 t = timeit(mask_then_wgrad)
 rec("threshold_backward pass + dense_wgrad (round 1's backward)", t, tflop=2.0 * n * d * d / 1e12)
 del yr
