@@ -40,12 +40,24 @@ __host__ __device__ inline BnGeom bn_geom(int d) {
 
 // MODE 0: a = sum(x - pivot), b = sum((x - pivot)^2)          (forward statistics)
 // MODE 1: a = sum(g),         b = sum(g * (x - pivot)),  g = dy * [y > 0] when y != nullptr, pivot = mean
+// the affine scale of the apply pass, from the ROUNDED invstd the forward hands out: the forward and a backward that
+// recomputes the activation from x get the same bits
+__host__ __device__ __forceinline__ float bn_scale(float gamma, float invstd) {
+  return (float)((double)gamma * (double)invstd);
+}
+
 template <int W, int MODE>
 __global__ __launch_bounds__(kBlock) void bn_colsum_kernel(const float* __restrict__ x, int64_t ldx,
                                                            const float* __restrict__ dy, int64_t lddy,
                                                            const float* __restrict__ y, int64_t ldy,
                                                            const float* __restrict__ pivot, int64_t N, int32_t d,
-                                                           int64_t rows_per_block, float* __restrict__ partial) {
+                                                           int64_t rows_per_block, float* __restrict__ partial,
+                                                           const float* __restrict__ mx_gamma = nullptr,
+                                                           const float* __restrict__ mx_beta = nullptr,
+                                                           const float* __restrict__ mx_invstd = nullptr) {
+  // mx_invstd != NULL (MODE 1): the ReLU mask [y > 0] is recomputed from x — y = relu(fmaf(x - mean, scale, beta))
+  // with scale = float(gamma * invstd), the forward's own expression on the forward's own operands, bit for bit —
+  // instead of reading y
   __shared__ float red[2][kBlock][W];
   const BnGeom g = bn_geom<W>(d);
   const int cgi = threadIdx.x % g.cg;
@@ -59,6 +71,17 @@ __global__ __launch_bounds__(kBlock) void bn_colsum_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < W; ++k) { a[k] = 0.f; b[k] = 0.f; pv[k] = 0.f; }
     if (on) load_vec<W>(pivot + c0, pv);
+    float sc[W], bt[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) { sc[k] = 0.f; bt[k] = 0.f; }
+    if (MODE == 1 && mx_invstd != nullptr && on) {
+#pragma unroll
+      for (int k = 0; k < W; ++k)
+        if (c0 + k < d) {
+          sc[k] = bn_scale(mx_gamma ? mx_gamma[c0 + k] : 1.f, mx_invstd[c0 + k]);
+          bt[k] = mx_beta ? mx_beta[c0 + k] : 0.f;
+        }
+    }
     if (on) {
       for (int64_t r = r0 + rli; r < r1; r += g.rl) {
         float xv[W];
@@ -73,7 +96,10 @@ __global__ __launch_bounds__(kBlock) void bn_colsum_kernel(const float* __restri
         } else {
           float gv[W];
           load_vec<W>(dy + r * lddy + c0, gv);
-          if (y != nullptr) {
+          if (mx_invstd != nullptr) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) gv[k] = fmaf(xv[k] - pv[k], sc[k], bt[k]) > 0.f ? gv[k] : 0.f;
+          } else if (y != nullptr) {
             float yv[W];
             load_vec<W>(y + r * ldy + c0, yv);
 #pragma unroll
@@ -160,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void bn_fwd_finalize_kernel(const float* __
   var_unbiased[c] = (float)(N > 1 ? var * (double)N / (double)(N - 1) : var);
   const double gm = gamma ? (double)gamma[c] : 1.0;
   const double bt = beta ? (double)beta[c] : 0.0;
-  scale[c] = (float)(gm * istd);
+  scale[c] = bn_scale(gamma ? gamma[c] : 1.f, (float)istd);
   shift[c] = (float)bt;                                   // the apply pass computes (x - mean) * scale + beta
 }
 
@@ -170,7 +196,8 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_finalize_kernel(const float* __
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, float* dgamma,
-                                                                 float* dbeta, float* A, float* B, float* Cc) {
+                                                                 float* dbeta, float* A, float* B, float* Cc,
+                                                                 float* fwd_scale) {
   int c;
   double sg, sgx;
   if (!bn_col_sums(partial, nblk, d, c, sg, sgx)) return;
@@ -185,6 +212,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_finalize_kernel(const float* __
   A[c] = (float)a;
   B[c] = (float)bb;
   Cc[c] = (float)(-a * sg / (double)N);                 // dx = A g + B (x - mean) + C
+  if (fwd_scale != nullptr) fwd_scale[c] = bn_scale(gamma ? gamma[c] : 1.f, invstd[c]);   // for the recomputed ReLU mask
 }
 
 // MODE 0: out = act((x - ctr) * p0 + p1)        MODE 1: out = p0 * g + p1 * (x - ctr) + p2,  g = dy * [y > 0]
@@ -195,7 +223,9 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
                                                           const float* __restrict__ p0, const float* __restrict__ p1,
                                                           const float* __restrict__ p2,
                                                           const float* __restrict__ ctr, int relu, int64_t N,
-                                                          int32_t d, float* __restrict__ out, int64_t ldo) {
+                                                          int32_t d, float* __restrict__ out, int64_t ldo,
+                                                          const float* __restrict__ mx_scale = nullptr,
+                                                          const float* __restrict__ mx_beta = nullptr) {
   const int groups = (d + W - 1) / W;
   const int64_t total = N * groups;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -218,7 +248,15 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restric
       float gv[W], cv[W];
       load_vec<W>(dy + r * lddy + c0, gv);
       load_vec<W>(p2 + c0, cv);
-      if (y != nullptr) {
+      if (mx_scale != nullptr) {      // the forward's activation, recomputed (see bn_colsum_kernel); the scale
+        float sck[W], btk[W];         // vector was rebuilt by the finalize kernel
+        load_vec<W>(mx_scale + c0, sck);
+#pragma unroll
+        for (int k = 0; k < W; ++k) btk[k] = 0.f;
+        if (mx_beta != nullptr) load_vec<W>(mx_beta + c0, btk);
+#pragma unroll
+        for (int k = 0; k < W; ++k) gv[k] = fmaf(xv[k], sck[k], btk[k]) > 0.f ? gv[k] : 0.f;
+      } else if (y != nullptr) {
         float yv[W];
         load_vec<W>(y + r * ldy + c0, yv);
 #pragma unroll
@@ -296,38 +334,57 @@ int mp_bn_train_fwd_f32(const float* x, int64_t ldx, int64_t N, int32_t d, const
   return MP_OK;
 }
 
-int mp_bn_train_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
-                        int64_t N, int32_t d, const float* gamma, const float* mean, const float* invstd,
-                        float* dx, int64_t lddx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                        mp_stream_t stream) {
+static int bn_bwd_common(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                         int64_t N, int32_t d, const float* gamma, const float* beta, int mask_from_x,
+                         const float* mean, const float* invstd, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                         void* ws, size_t ws_bytes, hipStream_t st) {
   if (N <= 0 || d <= 0 || !dy || !x || !mean || !invstd || !dx || lddy < d || ldx < d || lddx < d || (y && ldy < d))
     return MP_ERR_INVALID_ARG;
   BnWs L;
   bn_ws_layout(N, d, ws, &L);
   if (!ws || ws_bytes < L.total) return MP_ERR_WORKSPACE;
-  hipStream_t st = as_stream(stream);
   const int nblk = bn_blocks(N);
   const int64_t rpb = ceil_div(N, nblk);
   const bool vec = d % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (!y || ldy % 4 == 0) &&
-                   bn_al(x, 16) && bn_al(dy, 16) && bn_al(y, 16) && bn_al(dx, 16);
+                   bn_al(x, 16) && bn_al(dy, 16) && bn_al(y, 16) && bn_al(dx, 16) && (!mask_from_x || bn_al(beta, 16));
+  const float* mg = mask_from_x ? gamma : nullptr;
+  const float* mb = mask_from_x ? beta : nullptr;
+  const float* mi = mask_from_x ? invstd : nullptr;
   if (vec)
     hipLaunchKernelGGL((bn_colsum_kernel<4, 1>), dim3(nblk), dim3(kBlock), 0, st, x, ldx, dy, lddy, y, ldy, mean, N,
-                       d, rpb, L.partial);
+                       d, rpb, L.partial, mg, mb, mi);
   else
     hipLaunchKernelGGL((bn_colsum_kernel<1, 1>), dim3(nblk), dim3(kBlock), 0, st, x, ldx, dy, lddy, y, ldy, mean, N,
-                       d, rpb, L.partial);
+                       d, rpb, L.partial, mg, mb, mi);
   MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(d, 16)), dim3(kBlock), 0, st, L.partial, nblk,
-                     N, d, gamma, mean, invstd, dgamma, dbeta, L.v[0], L.v[1], L.v[2]);
+                     N, d, gamma, mean, invstd, dgamma, dbeta, L.v[0], L.v[1], L.v[2], mask_from_x ? L.v[3] : nullptr);
   MP_LAUNCH_CHECK();
+  const float* msc = mask_from_x ? L.v[3] : nullptr;
   if (vec)
     hipLaunchKernelGGL((bn_apply_kernel<4, 1>), dim3(flat_grid(N * (d / 4))), dim3(kBlock), 0, st, x, ldx, dy, lddy, y,
-                       ldy, L.v[0], L.v[1], L.v[2], mean, 0, N, d, dx, lddx);
+                       ldy, L.v[0], L.v[1], L.v[2], mean, 0, N, d, dx, lddx, msc, mb);
   else
     hipLaunchKernelGGL((bn_apply_kernel<1, 1>), dim3(flat_grid(N * d)), dim3(kBlock), 0, st, x, ldx, dy, lddy, y, ldy,
-                       L.v[0], L.v[1], L.v[2], mean, 0, N, d, dx, lddx);
+                       L.v[0], L.v[1], L.v[2], mean, 0, N, d, dx, lddx, msc, mb);
   MP_LAUNCH_CHECK();
   return MP_OK;
+}
+
+int mp_bn_train_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                        int64_t N, int32_t d, const float* gamma, const float* mean, const float* invstd,
+                        float* dx, int64_t lddx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                        mp_stream_t stream) {
+  return bn_bwd_common(dy, lddy, y, ldy, x, ldx, N, d, gamma, nullptr, 0, mean, invstd, dx, lddx, dgamma, dbeta, ws,
+                       ws_bytes, as_stream(stream));
+}
+
+int mp_bn_train_bwd_relu_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t N, int32_t d,
+                             const float* gamma, const float* beta, const float* mean, const float* invstd,
+                             float* dx, int64_t lddx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                             mp_stream_t stream) {
+  return bn_bwd_common(dy, lddy, nullptr, 0, x, ldx, N, d, gamma, beta, 1, mean, invstd, dx, lddx, dgamma, dbeta, ws,
+                       ws_bytes, as_stream(stream));
 }
 
 }  // extern "C"

@@ -57,8 +57,10 @@ def _(x, weight, bias, eps, relu):
 
 @custom_op("mp::bn_bwd_raw", mutates_args=(), device_types="cuda")
 def _op_bn_bwd_raw(dy: Tensor, y: Optional[Tensor], x: Tensor, weight: Optional[Tensor], mean: Tensor,
-                   invstd: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
-    """(dx, dgamma, dbeta); y given = the forward's ReLU output (its mask is applied to dy on the fly)"""
+                   invstd: Tensor, bias: Optional[Tensor] = None,
+                   relu_from_x: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+    """(dx, dgamma, dbeta); y given = the forward's ReLU output (its mask is applied to dy on the fly); relu_from_x:
+    the mask is recomputed from x, weight, bias, mean, invstd instead (mp_bn_train_bwd_relu_f32: y is not read)"""
     x = x if (x.dtype == torch.float32 and x.stride(-1) == 1) else x.float().contiguous()
     N, d = x.shape
     dy = dy.contiguous()
@@ -68,14 +70,21 @@ def _op_bn_bwd_raw(dy: Tensor, y: Optional[Tensor], x: Tensor, weight: Optional[
     w = None if weight is None else weight.detach().contiguous()
     with torch.cuda.device(x.device):
         ws, nb = _bn_ws(N, d, x.device)
-        check(lib().mp_bn_train_bwd_f32(ptr(dy), dy.stride(0), ptr(y), y.stride(0) if y is not None else 0, ptr(x),
-                                        x.stride(0), N, d, ptr(w), ptr(mean), ptr(invstd), ptr(dx), dx.stride(0),
-                                        ptr(dgamma), ptr(dbeta), ptr(ws), nb, _stream()), "mp_bn_train_bwd_f32")
+        if relu_from_x:
+            b = None if bias is None else bias.detach().contiguous()
+            check(lib().mp_bn_train_bwd_relu_f32(ptr(dy), dy.stride(0), ptr(x), x.stride(0), N, d, ptr(w), ptr(b),
+                                                 ptr(mean), ptr(invstd), ptr(dx), dx.stride(0), ptr(dgamma),
+                                                 ptr(dbeta), ptr(ws), nb, _stream()), "mp_bn_train_bwd_relu_f32")
+        else:
+            check(lib().mp_bn_train_bwd_f32(ptr(dy), dy.stride(0), ptr(y), y.stride(0) if y is not None else 0,
+                                            ptr(x), x.stride(0), N, d, ptr(w), ptr(mean), ptr(invstd), ptr(dx),
+                                            dx.stride(0), ptr(dgamma), ptr(dbeta), ptr(ws), nb, _stream()),
+                  "mp_bn_train_bwd_f32")
     return dx, dgamma, dbeta
 
 
 @_op_bn_bwd_raw.register_fake
-def _(dy, y, x, weight, mean, invstd):
+def _(dy, y, x, weight, mean, invstd, bias=None, relu_from_x=False):
     d = x.size(1)
     return (x.new_empty(x.shape, dtype=torch.float32), x.new_empty((d,), dtype=torch.float32),
             x.new_empty((d,), dtype=torch.float32))
@@ -100,12 +109,13 @@ def _bn_setup(ctx, inputs, output):
     y, mean, invstd, _ = output
     ctx.relu = relu
     ctx.has_affine = (weight is not None, bias is not None)
-    ctx.save_for_backward(x, weight, mean, invstd, y if relu else None)
+    # the ReLU mask of the backward pass is recomputed from x (bit for bit the forward's): y is not kept for it
+    ctx.save_for_backward(x, weight, mean, invstd, bias if relu else None)
 
 
 def _bn_backward(ctx, dy, _dmean, _dinvstd, _dvar):
-    x, w, mean, invstd, y = ctx.saved_tensors
-    dx, dgamma, dbeta = torch.ops.mp.bn_bwd_raw(dy, y, x, w, mean, invstd)
+    x, w, mean, invstd, b = ctx.saved_tensors
+    dx, dgamma, dbeta = torch.ops.mp.bn_bwd_raw(dy, None, x, w, mean, invstd, b, ctx.relu)
     return dx, (dgamma if ctx.has_affine[0] else None), (dbeta if ctx.has_affine[1] else None), None, None
 
 

@@ -283,6 +283,14 @@ int mp_bn_train_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t l
                         const float* gamma, const float* mean, const float* invstd,
                         float* dx, int64_t lddx, float* dgamma, float* dbeta,
                         void* ws, size_t ws_bytes, mp_stream_t stream);
+/* The backward of BatchNorm + ReLU without the forward's output: the mask [y > 0] is recomputed from x —
+ * y = relu(fmaf(x - mean, float(gamma * invstd), beta)), the forward's own expression on the forward's own operands,
+ * so the mask is the forward's bit for bit — and the two passes read dy and x only (50 instead of 70 GB at
+ * 10^7 x 256).  gamma / beta NULL = 1 / 0. */
+int mp_bn_train_bwd_relu_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t N, int32_t d,
+                             const float* gamma, const float* beta, const float* mean, const float* invstd,
+                             float* dx, int64_t lddx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                             mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * Aggregate -> transform in one kernel                                *

@@ -77,3 +77,21 @@ def test_engine_linear_matches_torch_linear(dev):
                   (lin.bias.grad, g.sum(0), g.abs().sum(0))]
         for got, want, mag in checks:
             assert float(((got.double() - want).abs() / mag.clamp_min(1e-30)).max()) < 1e-5
+
+
+@pytest.mark.parametrize("N,d", [(1000, 256), (4097, 100), (333, 7), (50000, 64)])
+@pytest.mark.parametrize("affine", [(True, True), (True, False), (False, False)])
+def test_relu_mask_recomputed_from_x_is_the_forwards(dev, N, d, affine):
+    """mp_bn_train_bwd_relu_f32 (mask recomputed from x, y not read) gives the bits of mp_bn_train_bwd_f32 with the
+    forward's output as the mask: dx, dgamma and dbeta are torch.equal — including inputs that sit on the ReLU edge"""
+    g = torch.Generator().manual_seed(N * 7 + d)
+    x = (torch.randn(N, d, generator=g) * 2 + torch.randn(d, generator=g)).to(dev)
+    w = (torch.rand(d, generator=g) + 0.5).to(dev) if affine[0] else None
+    b = (torch.randn(d, generator=g) * 0.1).to(dev) if affine[1] else None
+    dy = torch.randn(N, d, generator=g).to(dev)
+    y, mean, invstd, _ = torch.ops.mp.bn_fwd_raw(x, w, b, 1e-5, True)
+    assert 0.2 < float((y > 0).float().mean()) < 0.8
+    a = torch.ops.mp.bn_bwd_raw(dy, y, x, w, mean, invstd)
+    c = torch.ops.mp.bn_bwd_raw(dy, None, x, w, mean, invstd, b, True)
+    for u, v, name in zip(a, c, ("dx", "dgamma", "dbeta")):
+        assert torch.equal(u, v), name
