@@ -69,6 +69,8 @@ PROTOTYPES = {
                                            _sz, _p]),
     "mp_agg_dense_f32": (C.c_int, [_p, _p, _p, _i64, C.c_int, _p, _i64, _i32, _p, _i64, C.c_float, _p, _i64, _i32, _p, C.c_int,
                                    _p, _p, _i64, _p, _i64, _p, _p]),
+    "mp_agg_dense_add_f32": (C.c_int, [_p, _p, _p, _i64, C.c_int, _p, _i64, _i32, _p, _i64, C.c_float, _p, _i64, _i32, _p,
+                                       C.c_int, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p]),
     "mp_id_fixup_f32": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i32, C.c_int, _p]),
     "mp_dense_fused_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _p, _p, C.c_int, _p, _i64, _i64, _i32, _i32, _p]),
     "mp_dense_x3_f32": (C.c_int, [_p, _i64, _p, _p, _i32, _p, _i64, _i64, _i32, _i32, _p]),

@@ -47,6 +47,7 @@ struct FusedArgs {
   const uint8_t* defer_act;   // [N] or NULL: rows with a nonzero flag are stored without the activation
   float* P; int64_t ldp;
   float* out; int64_t ldo; int32_t dout;
+  const float* R; int64_t ldr;   // optional residual added before the activation: out = act(acc + bias + R)
   int32_t out_vec4;   // out rows allow 16-byte stores
   int32_t mean;   // rows are divided by their entry count (applied to the saved P rows and in the output epilogue)
 };
@@ -217,6 +218,10 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
     auto finish = [&](int r, int rl) {
       const float sc = inv_deg[rl];
       f32x2 o = {fmaf(acc0[r], sc, bv[0]), fmaf(acc1[r], sc, bv[1])};
+      if (a.R != nullptr && col_ok && R0 + rl < R1) {
+        const f32x2 rv = *reinterpret_cast<const f32x2*>(a.R + (int64_t)(R0 + rl) * a.ldr + cpair);
+        o[0] += rv[0]; o[1] += rv[1];
+      }
       if (a.act == MP_ACT_RELU && !defer_l[rl]) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); }
       return o;
     };
@@ -452,13 +457,15 @@ using namespace mp;
 
 extern "C" {
 
-int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
-                     const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale, const float* W,
-                     int64_t ldw, int32_t d_out, const float* bias, int act, const uint8_t* defer_act, float* P,
-                     int64_t ldp, float* out, int64_t ldo, const void* W_split, mp_stream_t stream) {
+static int agg_dense_common(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
+                            const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale,
+                            const float* W, int64_t ldw, int32_t d_out, const float* bias, int act,
+                            const uint8_t* defer_act, float* P, int64_t ldp, float* out, int64_t ldo,
+                            const void* W_split, const float* R, int64_t ldr, mp_stream_t stream) {
   if (!rowptr || !X || !W || !out || N < 0 || F <= 0 || d_out <= 0) return MP_ERR_INVALID_ARG;
   if (W_split && ((uintptr_t)W_split % 16)) return MP_ERR_ALIGNMENT;
-  if (ldx < F || ldw < d_out || ldo < d_out || (S && lds < F) || (P && ldp < F)) return MP_ERR_INVALID_ARG;
+  if (ldx < F || ldw < d_out || ldo < d_out || (S && lds < F) || (P && ldp < F) || (R && ldr < d_out))
+    return MP_ERR_INVALID_ARG;
   if (act != MP_ACT_NONE && act != MP_ACT_RELU) return MP_ERR_INVALID_ARG;
   if (reduce != MP_SUM && reduce != MP_MEAN) return MP_ERR_INVALID_ARG;
   if (reduce == MP_MEAN && S) return MP_ERR_INVALID_ARG;
@@ -469,7 +476,7 @@ int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val
   const int w = F == 512 ? 4 : F / kWave;
   auto mis = [](const void* p, int64_t ld, int bytes) { return ((uintptr_t)p % bytes) || ((ld * 4) % bytes); };
   if (mis(X, ldx, 4 * w) || (S && mis(S, lds, 16)) || (P && mis(P, ldp, 16)) || mis(W, ldw, 8) || mis(out, ldo, 8) ||
-      (bias && ((uintptr_t)bias % 8)))
+      (bias && ((uintptr_t)bias % 8)) || (R && mis(R, ldr, 8)))
     return MP_ERR_ALIGNMENT;
   if (N == 0) return MP_OK;
   if (!col) return MP_ERR_INVALID_ARG;
@@ -479,6 +486,7 @@ int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val
   a.Wm = W; a.ldw = ldw; a.bias = bias; a.act = act; a.defer_act = defer_act;
   a.Wsp = reinterpret_cast<const __bf16*>(W_split); a.ldws = F;
   a.P = P; a.ldp = ldp; a.out = out; a.ldo = ldo; a.dout = d_out; a.mean = reduce == MP_MEAN;
+  a.R = R; a.ldr = ldr;
   a.out_vec4 = !mis(out, ldo, 16);
   hipStream_t st = as_stream(stream);
   if (F == 512) return launch_fused<4, 2, 2, 2>(a, st);   // (the one-block instantiation spills: the compiler's choice)
@@ -487,6 +495,24 @@ int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val
     case 2: return launch_fused<2, 1, 1, 1>(a, st);
     default: return launch_fused<1, 1, 1, 1>(a, st);
   }
+}
+
+int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
+                     const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale, const float* W,
+                     int64_t ldw, int32_t d_out, const float* bias, int act, const uint8_t* defer_act, float* P,
+                     int64_t ldp, float* out, int64_t ldo, const void* W_split, mp_stream_t stream) {
+  return agg_dense_common(rowptr, col, val, N, reduce, X, ldx, F, S, lds, self_scale, W, ldw, d_out, bias, act, defer_act,
+                          P, ldp, out, ldo, W_split, nullptr, 0, stream);
+}
+
+int mp_agg_dense_add_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
+                         const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale,
+                         const float* W, int64_t ldw, int32_t d_out, const float* bias, int act,
+                         const uint8_t* defer_act, float* P, int64_t ldp, float* out, int64_t ldo, const void* W_split,
+                         const float* R, int64_t ldr, mp_stream_t stream) {
+  if (!R) return MP_ERR_INVALID_ARG;
+  return agg_dense_common(rowptr, col, val, N, reduce, X, ldx, F, S, lds, self_scale, W, ldw, d_out, bias, act, defer_act,
+                          P, ldp, out, ldo, W_split, R, ldr, stream);
 }
 
 int mp_id_fixup_f32(const int32_t* rows, const int32_t* crp, const int32_t* slot, const float* val, int64_t n_rows,

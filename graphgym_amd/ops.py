@@ -193,7 +193,7 @@ def _split_bf16_t(W):
 
 
 def _raw_agg_dense(g, x, W, bias=None, relu=False, S=None, self_scale=0.0, want_P=False, reduce=_lib.SUM,
-                   out=None, defer_act=None, bf16x3=None):
+                   out=None, defer_act=None, bf16x3=None, residual=None):
     """out = act((reduce_j w_ij x[j] + self_scale * S) W + bias) in one launch (into the view `out` when given);
     returns (out, P or None) with P the aggregated rows; defer_act [N] uint8: rows stored without the activation.
     bf16x3: run the product on the bf16 matrix pipe with three-way split operands (fp32-accurate, 3/8 of the MFMA
@@ -209,12 +209,14 @@ def _raw_agg_dense(g, x, W, bias=None, relu=False, S=None, self_scale=0.0, want_
         out = placement.empty_or_torch((N, d), x.device, reads=(x,))
     P = placement.empty_or_torch((N, F), x.device, reads=(x,)) if want_P else None
     with torch.cuda.device(x.device):
-        check(L.mp_agg_dense_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val), N, reduce, ptr(x), x.stride(0), F,
-                                 ptr(S), S.stride(0) if S is not None else 0, float(self_scale), ptr(Wc),
-                                 Wc.stride(0), d, ptr(b), _lib.ACT_RELU if relu else _lib.ACT_NONE, ptr(defer_act),
-                                 ptr(P), P.stride(0) if P is not None else 0, ptr(out), out.stride(0), ptr(Wsp),
-                                 _stream()),
-              "mp_agg_dense_f32")
+        args = (ptr(g.rowptr), ptr(g.col), ptr(g.val), N, reduce, ptr(x), x.stride(0), F,
+                ptr(S), S.stride(0) if S is not None else 0, float(self_scale), ptr(Wc),
+                Wc.stride(0), d, ptr(b), _lib.ACT_RELU if relu else _lib.ACT_NONE, ptr(defer_act),
+                ptr(P), P.stride(0) if P is not None else 0, ptr(out), out.stride(0), ptr(Wsp))
+        if residual is None:
+            check(L.mp_agg_dense_f32(*args, _stream()), "mp_agg_dense_f32")
+        else:   # out = act(... + residual); the residual may be `out` itself
+            check(L.mp_agg_dense_add_f32(*args, ptr(residual), residual.stride(0), _stream()), "mp_agg_dense_add_f32")
     return out, P
 
 
@@ -238,7 +240,7 @@ def _raw_dense_wgrad(P, G, want_bias=False):
     return (out, db) if want_bias else out
 
 
-def _raw_dense_wgrad_relu(P, G, Y, want_bias=False, want_gm=True):
+def _raw_dense_wgrad_relu(P, G, Y, want_bias=False, want_gm=True, gm_out=None):
     """(P^T (G * [Y > 0]), its column sums or None, G * [Y > 0]) in one pass (mp_dense_wgrad_relu_f32): the weight-gradient
     kernel masks the incoming gradient by the forward's ReLU pattern as it reads it and writes the masked gradient out
     for the input-gradient launch; None when the shape is outside the kernel"""
@@ -248,7 +250,9 @@ def _raw_dense_wgrad_relu(P, G, Y, want_bias=False, want_gm=True):
     out = torch.empty((F, d), dtype=torch.float32, device=P.device)
     db = torch.empty(d, dtype=torch.float32, device=P.device) if want_bias else None
     # the masked gradient is written only when an input-gradient launch will read it (a first layer has none)
-    gm = placement.empty_or_torch((M, d), P.device, reads=(G, Y, P)) if want_gm else None
+    # (gm_out: a [M, d] view to receive it, e.g. one half of a concatenated gradient)
+    gm = gm_out if gm_out is not None else (
+        placement.empty_or_torch((M, d), P.device, reads=(G, Y, P)) if want_gm else None)
     with torch.cuda.device(P.device):
         nb = C.c_size_t(0)
         check(L.mp_dense_wgrad_ws_bytes(M, F, d, C.byref(nb)))
@@ -311,15 +315,28 @@ class _ConcatDense(torch.autograd.Function):
     def backward(ctx, g):
         x, m, Ws, Wn, out = ctx.saved_tensors
         ku = ctx.ku
-        if ctx.relu:
-            g = torch.ops.aten.threshold_backward(g, out, 0.0)
         g = g.contiguous()
-        gs, gn = g[:, :ku], g[:, ku:]                      # strided views: the kernels take leading dimensions
-
-        dx = times_wt(gs, Ws) if ctx.needs_input_grad[0] else None
-        dm = times_wt(gn, Wn) if ctx.needs_input_grad[1] else None
-        dWs, dbs = _wgrad_and_bias(x, gs, ctx.needs_input_grad[2], ctx.has_bias)
-        dWn, dbn = _wgrad_and_bias(m, gn, ctx.needs_input_grad[3], ctx.has_bias)
+        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        done = False
+        if ctx.relu and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
+            # the ReLU mask rides in the two weight-gradient passes (one per half of the output); the masked halves are
+            # written only when an input gradient will read them (a first layer has none)
+            mg = torch.empty_like(g) if need_in else None
+            rs = _raw_dense_wgrad_relu(x, g[:, :ku], out[:, :ku], want_bias=ctx.has_bias, want_gm=need_in,
+                                       gm_out=None if mg is None else mg[:, :ku])
+            rn = None if rs is None else _raw_dense_wgrad_relu(m, g[:, ku:], out[:, ku:], want_bias=ctx.has_bias,
+                                                               want_gm=need_in,
+                                                               gm_out=None if mg is None else mg[:, ku:])
+            if rs is not None and rn is not None:
+                (dWs, dbs, _), (dWn, dbn, _) = rs, rn
+                g, done = mg, True
+        if not done:
+            if ctx.relu:
+                g = torch.ops.aten.threshold_backward(g, out, 0.0)
+            dWs, dbs = _wgrad_and_bias(x, g[:, :ku], ctx.needs_input_grad[2], ctx.has_bias)
+            dWn, dbn = _wgrad_and_bias(m, g[:, ku:], ctx.needs_input_grad[3], ctx.has_bias)
+        dx = times_wt(g[:, :ku], Ws) if ctx.needs_input_grad[0] else None     # strided views: the kernels take leading dimensions
+        dm = times_wt(g[:, ku:], Wn) if ctx.needs_input_grad[1] else None
         db = torch.cat([dbs, dbn]) if ctx.has_bias else None
         return dx, dm, dWs, dWn, db, None
 
@@ -351,24 +368,38 @@ class _SageConcatFused(torch.autograd.Function):
         x, P, Ws, Wn, out = ctx.saved_tensors
         ku = ctx.ku
         gm = gout.contiguous()
-        if ctx.relu:
-            gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
-        gs, gn = gm[:, :ku], gm[:, ku:]
-
-        dWs, dbs = _wgrad_and_bias(x, gs, ctx.needs_input_grad[1], ctx.has_bias)
-        dWn, dbn = _wgrad_and_bias(P, gn, ctx.needs_input_grad[2], ctx.has_bias)
+        done = False
+        if ctx.relu and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and P is not None:
+            # the ReLU mask rides in the two weight-gradient passes (one per half of the concatenated output), which
+            # also leave the masked halves in one buffer for the input-gradient launches: no threshold_backward pass
+            need_gm = ctx.needs_input_grad[0]
+            mg = torch.empty_like(gm) if need_gm else None
+            rs = _raw_dense_wgrad_relu(x, gm[:, :ku], out[:, :ku], want_bias=ctx.has_bias, want_gm=need_gm,
+                                       gm_out=None if mg is None else mg[:, :ku])
+            rn = None if rs is None else _raw_dense_wgrad_relu(P, gm[:, ku:], out[:, ku:], want_bias=ctx.has_bias,
+                                                               want_gm=need_gm,
+                                                               gm_out=None if mg is None else mg[:, ku:])
+            if rs is not None and rn is not None:
+                (dWs, dbs, _), (dWn, dbn, _) = rs, rn
+                gm, done = mg, True
+        if not done:
+            if ctx.relu:
+                gm = torch.ops.aten.threshold_backward(gm, out, 0.0)
+            dWs, dbs = _wgrad_and_bias(x, gm[:, :ku], ctx.needs_input_grad[1], ctx.has_bias)
+            dWn, dbn = _wgrad_and_bias(P, gm[:, ku:], ctx.needs_input_grad[2], ctx.has_bias)
+        gs, gn = (gm[:, :ku], gm[:, ku:]) if gm is not None else (None, None)
         db = torch.cat([dbs, dbn]) if ctx.has_bias else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = times_wt(gs, Ws)
             gt = ctx.g.transpose_mean()
             Wnt = Wn.detach().t().contiguous()
-            if agg_dense_supported(gt, gn, Wnt):
-                dn, _ = _raw_agg_dense(gt, gn, Wnt)
+            if agg_dense_supported(gt, gn, Wnt) and dx.stride(1) == 1 and dx.stride(0) % 2 == 0:
+                # dx = gs Ws^T + (A^T gn) Wn^T: the second term's launch adds the first as it stores
+                _raw_agg_dense(gt, gn, Wnt, out=dx, residual=dx)
             else:
                 T, _ = _raw_spmm(gt, gn.contiguous(), _lib.SUM)
-                dn = T @ Wnt
-            dx.add_(dn)
+                dx.add_(T @ Wnt)
         return dx, dWs, dWn, db, None, None, None
 
 

@@ -315,6 +315,17 @@ int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val
                      int64_t ldw, int32_t d_out, const float* bias, int act, const uint8_t* defer_act, float* P,
                      int64_t ldp, float* out, int64_t ldo, const void* W_split, mp_stream_t stream);
 
+/* The same with a residual added before the activation: out = act((A X + self_scale * S) W + bias + R), R [N, d_out]
+ * (ldr; 8-byte aligned rows; may be `out` itself: every element is read before it is written, by the same lane).  The
+ * input gradient of a concatenating layer — dx = g_self W_self^T + (A^T g_nbr) W_nbr^T (MeanGraphSage,
+ * TfgIDLayer.py:100-117) — is this call with R = g_self W_self^T, instead of an extra read-read-write pass over
+ * [N, d]. */
+int mp_agg_dense_add_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
+                         const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale,
+                         const float* W, int64_t ldw, int32_t d_out, const float* bias, int act,
+                         const uint8_t* defer_act, float* P, int64_t ldp, float* out, int64_t ldo, const void* W_split,
+                         const float* R, int64_t ldr, mp_stream_t stream);
+
 /* The identity branch of the ID layers on top of mp_agg_dense_f32: out = act(A (X W + S X W_id) + b)
  * (gcn_id, TfgIDLayer.py:510-523; GCNIDConvLayer.forward, idconv.py:150-177) equals
  * act((A X) W + b + A_id Z) with Z = X[id] W_id (n_id rows: a small product the caller makes) and A_id the stored

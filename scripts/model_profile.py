@@ -17,6 +17,6 @@ ids = torch.arange(0, n, 100, device=dev)
 def fl():
     inputs = [x, ei] + ([ids] if model.with_id else [])
     return H.tfg_loss(model(inputs, holder=holder), idx, labels, model.kernel_parameters())
-for _ in range(3):
+for _ in range(5):      # scripts/step_window.py takes the last two
     H.train_step(model, opt, fl)
 torch.cuda.synchronize()

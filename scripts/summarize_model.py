@@ -3,28 +3,30 @@
 
     python scripts/summarize_model.py gpurun_out/model_gin r02 gin
 
-ms_per_step = total duration / 3 (model_profile.py runs three training steps and one graph build); the copies of
-the one-off placement calibration (mp::arena_copy_kernel) are left out."""
+Reads steady.csv (scripts/step_window.py: the last two of model_profile.py's five steps, bounded by launches of the loss
+kernel), so the graph build, the placement calibration and first-call effects are outside the window."""
 import csv
 import os
 import sys
 
 src, tag, kind = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rows = [r for r in csv.DictReader(open(os.path.join(src, "stats.csv"))) if "arena_copy_kernel" not in r["Name"]]
-total = sum(float(r["TotalDurationNs"]) for r in rows) / 3e6
+rows = list(csv.DictReader(open(os.path.join(src, "steady.csv"))))
+steps = int(rows[0]["Steps"])
+total = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
+wall = float(rows[0]["WindowNs"]) / steps / 1e6
 worst = max(rows, key=lambda r: float(r["MaxNs"]) / max(float(r["MinNs"]), 1.0) if float(r["MaxNs"]) > 2e6 else 0)
 path = os.path.join(ROOT, "profiles", f"{tag}_{kind}_step_kernels.csv")
 with open(path, "w", newline="") as f:
-    f.write(f'"# rocprofv3 --kernel-trace --stats of scripts/model_profile.py KIND={kind} (3 training steps at N=1e7, '
-            f'd=256, incl. one graph build; the one-off placement calibration copies are left out); total '
-            f'{total:.1f} ms of kernels per step; largest max/min spread of a >2 ms kernel: '
+    f.write(f'"# rocprofv3 --kernel-trace of scripts/model_profile.py KIND={kind} (N=1e7, d=256): the last {steps} of 5 '
+            f'training steps (scripts/step_window.py), {total:.1f} ms of kernels per step in {wall:.1f} ms of wall time '
+            f'per step under the profiler; largest max/min spread of a >2 ms kernel: '
             f'{float(worst["MaxNs"]) / float(worst["MinNs"]):.2f}x"\n')
     w = csv.writer(f)
-    w.writerow(["kernel", "calls_in_3_steps", "ms_per_step", "percent"])
+    w.writerow(["kernel", f"calls_in_{steps}_steps", "ms_per_step", "percent"])
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
         name = r["Name"] if len(r["Name"]) <= 140 else r["Name"][:137] + "..."
-        ms = float(r["TotalDurationNs"]) / 3e6
+        ms = float(r["TotalDurationNs"]) / steps / 1e6
         if ms < 0.05:
             continue
         w.writerow([name, r["Calls"], f"{ms:.2f}", f"{100 * ms / total:.2f}"])

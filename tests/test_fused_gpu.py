@@ -395,3 +395,44 @@ def test_bf16x3_product_is_fp32_accurate(dev, n, E, F, d, weighted, hubs):
     assert e_split <= 4 * e_exact + 1e-7 * float(ref.abs().max()), (e_split, e_exact)
     split2, _ = ops._raw_agg_dense(G, x.to(dev), W.to(dev), b.to(dev), False, bf16x3=True)
     assert torch.equal(split, split2)
+
+
+def test_agg_dense_with_a_residual(dev):
+    """mp_agg_dense_add_f32: out = act((A X) W + b + R) equals the plain launch followed by an add, bit for bit without
+    an activation, also when R is the output buffer itself; and the MeanGraphSage backward uses it (no add pass, no
+    threshold_backward pass) while its gradients stay with float64 (test_sage_concat_fused_matches_oracle)"""
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    from torch.utils._python_dispatch import TorchDispatchMode
+    n, F, d = 4000, 128, 96
+    ei, w = make_graph(n, 50000, seed=21, hubs=True, weighted=True)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, F, generator=gen).to(dev)
+    W = (torch.randn(F, d, generator=gen) / F ** 0.5).to(dev)
+    b = torch.randn(d, generator=gen).to(dev)
+    R = torch.randn(n, d, generator=gen).to(dev)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, w.to(dev), dst_row=0)
+    plain, _ = ops._raw_agg_dense(G, x, W, b, False)
+    added, _ = ops._raw_agg_dense(G, x, W, b, False, residual=R)
+    assert torch.equal(added, plain + R)
+    buf = R.clone()
+    ops._raw_agg_dense(G, x, W, b, False, out=buf, residual=buf)          # in place
+    assert torch.equal(buf, added)
+    act, _ = ops._raw_agg_dense(G, x, W, b, True, residual=R)            # the activation comes after the residual
+    assert torch.equal(act, torch.relu(added))
+
+    seen = []
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+    xs = torch.randn(n, 128, generator=gen).to(dev).requires_grad_(True)
+    Ws = (torch.randn(128, 64, generator=gen) / 11).to(dev).requires_grad_(True)
+    Wn = (torch.randn(128, 64, generator=gen) / 11).to(dev).requires_grad_(True)
+    bs = torch.randn(128, generator=gen).to(dev).requires_grad_(True)
+    out = ops.sage_concat(G, xs, Ws, Wn, bs, relu=True)
+    with Spy():
+        out.sum().backward()
+    assert not any("threshold_backward" in s for s in seen), seen
+    assert not any("aten.add_" in s for s in seen), seen
