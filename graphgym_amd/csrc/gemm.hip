@@ -633,6 +633,89 @@ __global__ __launch_bounds__(kBlock) void narrow_wgrad_vec_kernel(const float* _
   }
 }
 
+// Narrow OUTPUTS (d <= 16: the classifier head, 256 -> 7 / 10 classes): dW[f, :] = sum_m P[m, f] g[m, :] is a stream
+// over P with d FMAs per element — HBM-bound (10 GB at 10^7 x 256), and the library's split-K GEMM for it runs at
+// 1.4 TB/s (7.2 ms).  A thread owns four adjacent f columns and all d outputs (4 x 16 accumulators); the block's row
+// lanes take rows round-robin and are added in lane order at the end; g rows are broadcast loads.
+__global__ __launch_bounds__(kBlock) void narrow_out_wgrad_kernel(const float* __restrict__ P, int64_t ldp,
+                                                                  const float* __restrict__ G, int64_t ldg, int64_t M,
+                                                                  int32_t F, int32_t d, int64_t chunk,
+                                                                  float* __restrict__ slabs,
+                                                                  float* __restrict__ bias_slabs) {
+  __shared__ float red[64][4][17];              // [column group][f][d (+ pad)]; bias partials in red[0][0][..] afterwards
+  const int ncg = F >> 2;                       // column groups handled per pass (<= 64: F <= 256 per pass)
+  const int64_t ch = blockIdx.x;
+  const int64_t mb = ch * chunk;
+  const int64_t me = mb + chunk < M ? mb + chunk : M;
+  float* slab = slabs + ch * (int64_t)F * d;
+  for (int cg0 = 0; cg0 < ncg; cg0 += 64) {     // F > 256: further passes over the rows
+    const int ng = ncg - cg0 < 64 ? ncg - cg0 : 64;
+    const int nrl = kBlock / 64;                // 4 row lanes
+    const int cgi = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const bool on = cgi < ng;
+    const int f0 = 4 * (cg0 + cgi);
+    float acc[4][16];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[f][j] = 0.f;
+    float bs[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bs[j] = 0.f;
+    constexpr int UR = 4;
+    for (int64_t m0 = mb + rl; m0 < me; m0 += (int64_t)UR * nrl) {
+      f32x4 pv[UR];
+      float gv[UR][16];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        int64_t m = m0 + (int64_t)u * nrl;
+        m = m < me ? m : me - 1;                // a clamped row is loaded and dropped below
+        pv[u] = on ? *reinterpret_cast<const f32x4*>(P + m * ldp + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gv[u][j] = G[m * ldg + (j < d ? j : d - 1)];   // one address per row lane
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        if (m0 + (int64_t)u * nrl < me) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            bs[j] += gv[u][j];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f][j] = fmaf(pv[u][f], gv[u][j], acc[f][j]);
+          }
+        }
+      }
+    }
+    // the four row lanes add up in lane order
+    for (int r = 0; r < nrl; ++r) {
+      if (rl == r && on) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) red[cgi][f][j] = (r == 0 ? 0.f : red[cgi][f][j]) + acc[f][j];
+      }
+      __syncthreads();
+    }
+    if (rl == 0 && on) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        for (int j = 0; j < d; ++j) slab[(int64_t)(f0 + f) * d + j] = red[cgi][f][j];
+    }
+    __syncthreads();
+    if (bias_slabs != nullptr && cg0 == 0) {    // column sums of g: every thread of a row lane holds the same partial
+      for (int r = 0; r < nrl; ++r) {
+        if (rl == r && cgi == 0) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) red[0][0][j] = (r == 0 ? 0.f : red[0][0][j]) + bs[j];
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x < d) bias_slabs[ch * (int64_t)d + threadIdx.x] = red[0][0][threadIdx.x];
+      __syncthreads();
+    }
+  }
+}
+
 // out[i] = sum over slabs of slabs[c][i], in a fixed order (bitwise reproducible): a workgroup owns 16 consecutive
 // elements, its 16 slab lanes each add every 16th slab through four independent running sums, and the 64 partial sums
 // of an element are combined lane by lane.  (One thread per element walking all slabs in a dependent chain took 1.8 ms
@@ -666,9 +749,10 @@ __global__ __launch_bounds__(kBlock) void slab_reduce_kernel(const float* __rest
   }
 }
 
-static int64_t wgrad_chunk(int64_t M, int32_t F) {
+static int64_t wgrad_chunk(int64_t M, int32_t F, int32_t d) {
   // narrow inputs: a slab is F * d floats, so many small chunks cost nothing and balance the chip
   if (F <= 8) return 2048;
+  if (d <= 16) return 4096;                     // narrow outputs: likewise
   // enough chunks to fill the chip with 128 x 128 tiles, few enough that the slab pass stays small
   int64_t chunk = 4096;
   while (chunk < 65536 && ceil_div(M, chunk) > 1024) chunk *= 2;
@@ -711,7 +795,7 @@ int mp_dense_fused_f32(const float* P, int64_t ldp, const float* W, const float*
 
 int mp_dense_wgrad_ws_bytes(int64_t M, int32_t F, int32_t d, size_t* bytes_host) {
   if (!bytes_host || M < 0 || F <= 0 || d <= 0) return MP_ERR_INVALID_ARG;
-  *bytes_host = (size_t)ceil_div(M > 0 ? M : 1, wgrad_chunk(M, F)) * ((size_t)F * d + d) * 4;   // + the bias partials
+  *bytes_host = (size_t)ceil_div(M > 0 ? M : 1, wgrad_chunk(M, F, d)) * ((size_t)F * d + d) * 4;   // + the bias partials
   return MP_OK;
 }
 
@@ -728,7 +812,7 @@ static int wgrad_common(const float* P, int64_t ldp, const float* G, int64_t ldg
   }
   const bool vec = !(F % 4 || d % 4 || ldp % 4 || ldg % 4 || (Y && ldy % 4) || (GM && ldgm % 4)) && al16(P) &&
                    al16(G) && al16(Y) && al16(GM);
-  const int64_t chunk = wgrad_chunk(M, F);
+  const int64_t chunk = wgrad_chunk(M, F, d);
   const int64_t n_chunk = ceil_div(M, chunk);
   const size_t need = (size_t)n_chunk * ((size_t)F * d + d) * 4;
   if (!ws || ws_bytes < need) return MP_ERR_WORKSPACE;
@@ -753,6 +837,20 @@ static int wgrad_common(const float* P, int64_t ldp, const float* G, int64_t ldg
     else
       hipLaunchKernelGGL(narrow_wgrad_kernel<false>, ngrid, dim3(kBlock), 0, st, P, ldp, G, ldg, Y, ldy, GM, ldgm, M,
                          F, d, chunk, (float*)ws, bias_slabs);
+    MP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)F * d * 16)), dim3(kBlock), 0, st, (const float*)ws,
+                       n_chunk, (int64_t)F * d, dW);
+    MP_LAUNCH_CHECK();
+    if (dbias) {
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)d * 16)), dim3(kBlock), 0, st,
+                         (const float*)bias_slabs, n_chunk, (int64_t)d, dbias);
+      MP_LAUNCH_CHECK();
+    }
+    return MP_OK;
+  }
+  if (!Y && d <= 16 && F % 4 == 0 && ldp % 4 == 0 && al16(P)) {   // the classifier head's shape
+    hipLaunchKernelGGL(narrow_out_wgrad_kernel, dim3((unsigned)n_chunk), dim3(kBlock), 0, st, P, ldp, G, ldg, M, F, d,
+                       chunk, (float*)ws, bias_slabs);
     MP_LAUNCH_CHECK();
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)F * d * 16)), dim3(kBlock), 0, st, (const float*)ws,
                        n_chunk, (int64_t)F * d, dW);

@@ -224,6 +224,27 @@ class BatchNorm1d(nn.BatchNorm1d):
         return super().extra_repr() + f", relu={self.relu}"
 
 
+class _NarrowHead(torch.autograd.Function):
+    """y = x W^T + b for a narrow output (a classifier head, <= 16 classes) over many rows: the products with a
+    [N, <= 16] side are the library's (they stream at the HBM rate), the weight gradient x^T g is the engine's
+    narrow-output kernel (mp_dense_wgrad_f32: 10 GB at the HBM rate; the library's split-K GEMM takes 7.2 ms for it at
+    10^7 x 256 x 10) with the bias gradient out of the same pass"""
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.mm(g, weight) if ctx.needs_input_grad[0] else None
+        dW, db = ops._wgrad_and_bias(x, g, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        return dx, (None if dW is None else dW.t()), db
+
+
 class Linear(nn.Linear):
     """torch.nn.Linear (same parameters, same state dict) whose forward is the engine's transform kernel with bias
     and an optional ReLU fused into the store — the keras Dense(d, relu) / Dense(d) of the TF path's MLPs
@@ -239,6 +260,10 @@ class Linear(nn.Linear):
         # the engine's kernels pay off on wide outputs over many rows (scripts/linear_bench.py: forward + backward
         # 39.8 vs 45.0 ms at 10^7 x 256 -> 256, 18.6 vs 27.8 ms at 1 -> 256; the library wins at 256 -> 10 and on
         # small batches), so narrow heads and small inputs stay on the library
+        if (x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and self.out_features <= 16 and not self.relu
+                and self.in_features % 4 == 0 and x.size(0) >= (1 << 17) and x.stride(1) == 1 and x.stride(0) % 4 == 0
+                and x.data_ptr() % 16 == 0 and torch.is_grad_enabled()):
+            return _NarrowHead.apply(x, self.weight, self.bias)
         if (x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or self.out_features < 32
                 or x.size(0) * self.out_features < (1 << 23)):
             y = F.linear(x, self.weight, self.bias)

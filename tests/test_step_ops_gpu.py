@@ -93,3 +93,38 @@ def test_softmax_cross_entropy_matches_torch(dev, subset):
     lab_idx = torch.arange(N, device=dev) if idx is None else idx.to(dev)
     l2 = H.tfg_loss(zd.detach(), lab_idx, y.to(dev), [])
     assert abs(float(l2) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+
+
+@pytest.mark.parametrize("M,Fi,d", [(5000, 256, 10), (4099, 64, 7), (70000, 128, 16), (3000, 512, 3), (100, 4, 1)])
+def test_narrow_output_weight_gradient(dev, M, Fi, d):
+    """the classifier head's weight gradient x^T g (d <= 16 columns) on the engine's narrow-output kernel, with the bias
+    gradient from the same pass, against float64"""
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(M + d)
+    P = torch.randn(M, Fi, generator=g)
+    G = torch.randn(M, d, generator=g)
+    dW, db = ops._raw_dense_wgrad(P.to(dev), G.to(dev), want_bias=True)
+    assert_close_all(dW, P.double().t() @ G.double(), 1e-5, ref32=P.t() @ G, what="dW")
+    assert_close_all(db, G.double().sum(0), 1e-5, ref32=G.sum(0), what="db")
+    dW2, db2 = ops._raw_dense_wgrad(P.to(dev), G.to(dev), want_bias=True)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)                # fixed summation order
+
+
+def test_narrow_head_linear_backward(dev):
+    """graphgym_amd.nn.Linear with <= 16 outputs over many rows: same gradients as torch.nn.Linear in float64"""
+    from graphgym_amd import nn as mpnn
+    g = torch.Generator().manual_seed(9)
+    N = 1 << 17
+    x = torch.randn(N, 64, generator=g)
+    lin = mpnn.Linear(64, 10).to(dev)
+    ref = torch.nn.Linear(64, 10).double()
+    with torch.no_grad():
+        ref.weight.copy_(lin.weight.detach().cpu().double()); ref.bias.copy_(lin.bias.detach().cpu().double())
+    xd = x.to(dev).requires_grad_(True)
+    up = torch.randn(N, 10, generator=g)
+    lin(xd).backward(up.to(dev))
+    xr = x.double().requires_grad_(True)
+    ref(xr).backward(up.double())
+    assert_close_all(lin.weight.grad, ref.weight.grad, 1e-5, ref32=(up.t() @ x), what="dW")
+    assert_close_all(lin.bias.grad, ref.bias.grad, 1e-5, ref32=up.sum(0), what="db")
+    assert_close_all(xd.grad, xr.grad, 1e-5, what="dx")
