@@ -967,6 +967,7 @@ def _(x, graph, reduce, self_scale, bias, relu):
 
 
 def _spmm_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)   # unused outputs (the saved rows, argmax) get no zero-filled gradient tensors
     x, graph, reduce, self_scale, bias, relu = inputs
     y, argmax = output
     ctx.graph, ctx.reduce, ctx.self_scale, ctx.relu = graph, reduce, self_scale, relu
@@ -977,6 +978,8 @@ def _spmm_setup(ctx, inputs, output):
 
 def _spmm_backward(ctx, dy, _dargmax):
     y, argmax = ctx.saved_tensors
+    if dy is None:
+        return None, None, None, None, None, None
     dy = dy.contiguous()
     if ctx.relu:
         dy = torch.ops.aten.threshold_backward(dy, y, 0.0)    # one vectorised pass
@@ -1018,6 +1021,7 @@ def _(x, graph, id_index):
 
 
 def _idgnn_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)   # unused outputs (the saved rows, argmax) get no zero-filled gradient tensors
     x, graph, id_index = inputs
     ctx.graph, ctx.g_alive = graph, from_handle(graph)
     ctx.save_for_backward(id_index)
@@ -1025,7 +1029,13 @@ def _idgnn_setup(ctx, inputs, output):
 
 def _idgnn_backward(ctx, dP, dQ):
     (id_index,) = ctx.saved_tensors
+    if dP is None and dQ is None:
+        return None, None, None
+    if dP is None:                            # only Q was used downstream
+        dP = torch.zeros_like(dQ)
     dx = torch.ops.mp.spmm_raw(dP.contiguous(), ctx.graph, 1, _lib.SUM, None, 0.0, None, False, False)[0]
+    if dQ is None:
+        return dx, None, None
     # Q = A S x  =>  dx[id] += (A^T dQ)[id]: only the identity nodes' rows of A^T are needed, an
     # aggregation over their out-edges alone (an [n_id, N] operator), not a second full pass
     t = torch.ops.mp.spmm_rows_raw(dQ.contiguous(), ctx.graph, 1, id_index)
@@ -1095,6 +1105,7 @@ def _(x, W, bias, graph, reduce, self_scale, relu, want_P):
 
 
 def _agg_dense_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)   # unused outputs (the saved rows, argmax) get no zero-filled gradient tensors
     x, W, bias, graph, reduce, self_scale, relu, want_P = inputs
     out, P = output
     ctx.graph, ctx.g_alive = graph, from_handle(graph)
@@ -1105,6 +1116,8 @@ def _agg_dense_setup(ctx, inputs, output):
 def _agg_dense_backward(ctx, gout, _gP):
     P, W, out, x = ctx.saved_tensors
     need = ctx.needs_input_grad
+    if gout is None:
+        return None, None, None, None, None, None, None, None
     if not ctx.want_P and (need[1]):   # the aggregated rows were not kept (called outside grad mode bookkeeping)
         P = torch.ops.mp.spmm_raw(x, ctx.graph, 0, ctx.reduce, x if ctx.self_scale != 0.0 else None, ctx.self_scale,
                                   None, False, False)[0]
@@ -1146,6 +1159,7 @@ def _(x, W, W_id, bias, graph, id_index, self_scale, relu, want_P):
 
 
 def _agg_dense_id_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)   # unused outputs (the saved rows, argmax) get no zero-filled gradient tensors
     x, W, W_id, bias, graph, id_index, self_scale, relu, want_P = inputs
     out, P, x_id = output
     ctx.graph, ctx.g_alive = graph, from_handle(graph)
@@ -1156,6 +1170,8 @@ def _agg_dense_id_setup(ctx, inputs, output):
 def _agg_dense_id_backward(ctx, gout, _gP, _gxid):
     P, W, W_id, x_id, id_index, out, x = ctx.saved_tensors
     need = ctx.needs_input_grad
+    if gout is None:
+        return None, None, None, None, None, None, None, None, None
     if not ctx.want_P and need[1]:
         P = torch.ops.mp.spmm_raw(x, ctx.graph, 0, _lib.SUM, x if ctx.self_scale != 0.0 else None, ctx.self_scale,
                                   None, False, False)[0]
