@@ -364,7 +364,9 @@ __global__ __launch_bounds__(kBlock, 3) void dense_wgrad_kernel(const float* __r
 // four and g, y and the masked-gradient output pass through a block ONCE per d tile instead of once per (f, d) tile
 // pair.  The kernel is bound by the issue of its vector memory instructions (section on dense_x3.hip in DESIGN.md):
 // per MFMA this form issues 40 % fewer with the ReLU mask, 25 % fewer without.  72 KiB LDS: two blocks per CU.
-template <bool RELU>
+// ABL: ablation bits for scripts/dbg/wgrad_ablate.hip only (1 no global loads after the first tile, 2 no split / LDS
+// stores, 4 no MFMAs, 8 no LDS fragment reads — timing experiments with wrong results); the library builds ABL = 0.
+template <bool RELU, int ABL = 0>
 __global__ __launch_bounds__(kBlock, 2) void dense_wgrad_wide_kernel(const float* __restrict__ P, int64_t ldp,
                                                                      const float* G, int64_t ldg,
                                                                      const float* __restrict__ Y, int64_t ldy,
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(kBlock, 2) void dense_wgrad_wide_kernel(const float
   __syncthreads();
   for (int64_t t = 0; t < ntiles; ++t) {
     const int buf = (int)(t & 1);
-    if (t + 1 < ntiles) {
+    if (t + 1 < ntiles && !(ABL & 1)) {
       fetch(mb + (t + 1) * BK);
       if (do_bias) tally();
     }
@@ -469,17 +471,27 @@ __global__ __launch_bounds__(kBlock, 2) void dense_wgrad_wide_kernel(const float
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) as[i][pl] = tr_read8(Pimg[buf][pl][wave >> 1], (wave & 1) * 64 + i * 32, lane);
+        for (int pl = 0; pl < 3; ++pl) {
+          if constexpr (ABL & 8) as[i][pl] = __builtin_bit_cast(bf16x8, rp[i][0] + rg[0]);
+          else as[i][pl] = tr_read8(Pimg[buf][pl][wave >> 1], (wave & 1) * 64 + i * 32, lane);
+        }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         bf16x8 b3[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b3[pl] = tr_read8(Gimg[buf][pl], j * 32, lane);
+        for (int pl = 0; pl < 3; ++pl) {
+          if constexpr (ABL & 8) b3[pl] = __builtin_bit_cast(bf16x8, rg[j & 1] + rp[0][1]);
+          else b3[pl] = tr_read8(Gimg[buf][pl], j * 32, lane);
+        }
+        if constexpr (ABL & 4) {
+          asm volatile("" ::"v"(b3[0]), "v"(b3[1]), "v"(b3[2]), "v"(as[0][0]), "v"(as[1][2]));
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) mfma6(acc[i][j], as[i], b3);
+          for (int i = 0; i < 2; ++i) mfma6(acc[i][j], as[i], b3);
+        }
       }
     }
-    if (t + 1 < ntiles) stash(buf ^ 1);
+    if (t + 1 < ntiles && !(ABL & 2)) stash(buf ^ 1);
     __syncthreads();
   }
   float* slab = slabs + c * (int64_t)F * d;
