@@ -201,6 +201,7 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
   if (lane == 0) carry_row[wave] = cont ? first_rl : -1;
 
   const int fr = lane & 31, kk = lane >> 5;
+  const int fr_c = fr, kk_c = kk;
   f32x16 acc[KH == 2 ? NCB : 1][2];
   if constexpr (KH == 2) {
 #pragma unroll
@@ -211,6 +212,12 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
 
   // epilogue of one 64-column block of this wave: bias, 1/deg for mean, activation, store
   auto store_block = [&](const f32x16& acc0, const f32x16& acc1, int n0) {
+    // the lane coordinates are re-derived here from opaque copies that depend on an accumulator value: the compiler
+    // otherwise computes the 16 - 20 row pointers of this epilogue BEFORE phase B, runs out of registers there and
+    // spills them — 41 KB of scratch written and re-read per 32-row tile, 12 GB per launch at 10^7 rows
+    // (rocprofv3 WRITE_SIZE 22.5 GB for a 10.2 GB output)
+    int fr = fr_c, kk = kk_c;
+    asm volatile("" : "+v"(fr), "+v"(kk) : "v"(acc0[0]), "v"(acc1[15]));
     const int cpair = n0 + 2 * fr;
     const bool col_ok = cpair < a.dout;
     f32x2 bv = {0.f, 0.f};
