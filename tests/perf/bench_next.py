@@ -5,7 +5,7 @@
      and a batch of centres on a 10^6-node graph
   3. one ID-GCN training step on an ego batch (config C3 shape, d = 128)
 
-    python tests/perf/bench_next.py > profiles/r01_next.jsonl
+    python tests/perf/bench_next.py > profiles/rNN_next.jsonl
 
 Lives under tests/ because it times the CPU oracle next to the engine (oracle/ is test infrastructure).
 """
