@@ -249,7 +249,8 @@ class Linear(nn.Linear):
     """torch.nn.Linear (same parameters, same state dict) whose forward is the engine's transform kernel with bias
     and an optional ReLU fused into the store — the keras Dense(d, relu) / Dense(d) of the TF path's MLPs
     (main_zd.py:181-186,214-225) and GraphGym's Linear -> ReLU -> Linear (idconv.py:432-435).  Backward: the weight
-    and bias gradients come from the engine's split-K kernel, g W' (a plain product) from the library GEMM."""
+    and bias gradients come from the engine's split-K kernel, g W' from the streaming transform with W^T (the library GEMM
+    outside its shapes)."""
 
     def __init__(self, in_features, out_features, bias=True, relu=False):
         super().__init__(in_features, out_features, bias=bias)
