@@ -196,7 +196,8 @@ __global__ __launch_bounds__(X3_THREADS, 1) void dense_x3_kernel(const float* __
     if (pre) read_split(n + 1, p3n);
 
     // W slice of step n + 1: its buffer was last read in step n - 1, which every wave has left.  Whatever follows it
-    // in this step may stay in flight past the wait below (vmcnt retires in issue order, loads and stores alike):
+    // in this step may stay in flight past the wait below (s_waitcnt vmcnt(N) waits for all but the N youngest vector
+    // memory operations — loads, stores and LDS-DMA count together, in issue order: MI355X_MICROARCH.md, cycle constants):
     int allow = 0;
     if (n + 1 < nsteps && !(ABL & 2)) issue_B(s1, (n + 1) & 1);
     if (s == 0 && n > 0) {
