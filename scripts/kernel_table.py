@@ -146,7 +146,7 @@ out = bn(xr); up = torch.rand_like(out)
 def bwd():
     o = bn(xr); o.backward(up); xr.grad = None
 t_fb = timeit(bwd)
-rec("batchnorm + ReLU backward (two passes)", t_fb - t_f, 7 * n * d * 4 / 1e9, note="time = (forward + backward) - forward")
+rec("batchnorm + ReLU backward (two passes; the mask is recomputed from x, y is not read)", t_fb - t_f, 5 * n * d * 4 / 1e9, note="time = (forward + backward) - forward")
 del out, up, xr
 # identity rows
 u = torch.rand(ids.numel(), d, device=dev)
