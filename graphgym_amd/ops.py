@@ -303,7 +303,7 @@ class _ConcatDense(torch.autograd.Function):
     def forward(ctx, x, m, Ws, Wn, bias, relu):
         x, m = _f32c(x, "x"), _f32c(m, "m")
         ku, kn = Ws.size(1), Wn.size(1)
-        out = torch.empty((x.size(0), ku + kn), dtype=torch.float32, device=x.device)
+        out = placement.empty_or_torch((x.size(0), ku + kn), x.device, reads=(x, m))
         b = None if bias is None else bias.detach()
         _dense_into(out[:, :ku], x, Ws.detach(), None if b is None else b[:ku], relu)
         _dense_into(out[:, ku:], m, Wn.detach(), None if b is None else b[ku:], relu)
@@ -321,7 +321,7 @@ class _ConcatDense(torch.autograd.Function):
         if ctx.relu and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
             # the ReLU mask rides in the two weight-gradient passes (one per half of the output); the masked halves are
             # written only when an input gradient will read them (a first layer has none)
-            mg = torch.empty_like(g) if need_in else None
+            mg = placement.empty_or_torch(tuple(g.shape), g.device, reads=(g, out)) if need_in else None
             rs = _raw_dense_wgrad_relu(x, g[:, :ku], out[:, :ku], want_bias=ctx.has_bias, want_gm=need_in,
                                        gm_out=None if mg is None else mg[:, :ku])
             rn = None if rs is None else _raw_dense_wgrad_relu(m, g[:, ku:], out[:, ku:], want_bias=ctx.has_bias,
@@ -353,7 +353,7 @@ class _SageConcatFused(torch.autograd.Function):
     def forward(ctx, x, Ws, Wn, bias, g, relu, grad_mode):
         x = _f32c(x, "x")
         ku, kn = Ws.size(1), Wn.size(1)
-        out = torch.empty((x.size(0), ku + kn), dtype=torch.float32, device=x.device)
+        out = placement.empty_or_torch((x.size(0), ku + kn), x.device, reads=(x,))
         b = None if bias is None else bias.detach()
         _dense_into(out[:, :ku], x, Ws.detach(), None if b is None else b[:ku], relu)
         _, P = _raw_agg_dense(g, x, Wn.detach(), None if b is None else b[ku:], relu,
@@ -373,7 +373,7 @@ class _SageConcatFused(torch.autograd.Function):
             # the ReLU mask rides in the two weight-gradient passes (one per half of the concatenated output), which
             # also leave the masked halves in one buffer for the input-gradient launches: no threshold_backward pass
             need_gm = ctx.needs_input_grad[0]
-            mg = torch.empty_like(gm) if need_gm else None
+            mg = placement.empty_or_torch(tuple(gm.shape), gm.device, reads=(gm, out)) if need_gm else None
             rs = _raw_dense_wgrad_relu(x, gm[:, :ku], out[:, :ku], want_bias=ctx.has_bias, want_gm=need_gm,
                                        gm_out=None if mg is None else mg[:, :ku])
             rn = None if rs is None else _raw_dense_wgrad_relu(P, gm[:, ku:], out[:, ku:], want_bias=ctx.has_bias,
