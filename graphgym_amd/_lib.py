@@ -78,8 +78,8 @@ PROTOTYPES = {
     "mp_dense_wgrad_ws_bytes": (C.c_int, [_i64, _i32, _i32, _psz]),
     "mp_dense_wgrad_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
     "mp_dense_wgrad_relu_f32": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
-    "mp_softmax_ce_rows_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _p, _p]),
-    "mp_softmax_ce_bwd_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _p, _f32, _p, _i64, _p]),
+    "mp_softmax_ce_rows_f32": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _i32, _p, _p]),
+    "mp_softmax_ce_bwd_f32": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _i32, _p, _f32, _p, _i64, _p]),
     "mp_rows_gather_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p]),
     "mp_rows_scatter_add_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p]),
     "mp_sddmm_dot_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _i32, _f32, _p, _p]),

@@ -12,10 +12,11 @@ def _defaults():
     cfg = types.SimpleNamespace()
     cfg.device = "auto"                      # config.py:33
     cfg.num_threads = 6                      # config.py:57
-    cfg.dataset = types.SimpleNamespace(transform="none", augment_feature=[])
+    cfg.dataset = types.SimpleNamespace(transform="none", augment_feature=[], task="node")
+    cfg.model = types.SimpleNamespace(graph_pooling="add", loss_fun="cross_entropy")      # config.py:285-301
     cfg.train = types.SimpleNamespace(batch_size=16)
     cfg.gnn = types.SimpleNamespace(
-        layers_pre_mp=0, layers_mp=2, layers_post_mp=0, dim_inner=16,
+        layers_pre_mp=0, layers_mp=2, layers_post_mp=1, dim_inner=16,
         layer_type="generalconv", stage_type="stack", batchnorm=True, act="relu",
         dropout=0.0, agg="add", flow="source_to_target", normalize_adj=False,
         self_msg="concat", att_heads=1, l2norm=True)                     # config.py:313-369

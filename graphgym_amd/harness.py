@@ -4,9 +4,10 @@ model shapes of the reference's two entry points and its training step order.
     TfgNodeModel   the eight keras models of main_zd.py:28-243 (n conv layers -> Flatten ->
                    Dense(256, relu) -> Dense(num_labels)); GCN / GAT families hard-code 3 layers
                    (main_zd.py:33-35,82-84), SAGE / GIN use cfg.gnn.layers_mp (:131-132,178-187)
-    GNNStack       graphgym/models/gnn.py:123-168 with stage 'stack': pre_mp linears ->
-                   layers_mp x GeneralLayer (conv -> BN -> dropout -> act, layer.py:16-47) ->
-                   row L2-normalise (gnn.py:79-80) -> node head MLP + label gather (head.py:19-37)
+    GNN            graphgym/models/gnn.py:123-168 with stage 'stack', module for module (the reference's own
+                   state dicts load with strict=True): pre_mp.Layer_i -> mp.layer{i} (GeneralLayer: conv -> BN ->
+                   dropout -> act, layer.py:16-47) -> row L2-normalise (gnn.py:79-80) -> post_mp.layer_post_mp
+                   (node head + label gather head.py:19-37, or graph head with ego add-pool head.py:96-119)
     train_step     zero_grad -> forward -> loss -> backward -> [gradient all-reduce] -> step
                    (graphgym/train.py:18-25, 47-56)
     tfg_loss       mean softmax-CE over node_label_index + 5e-4 * sum ||kernel||^2 / 2
@@ -97,7 +98,15 @@ def tfg_loss(logits, node_label_index, labels, kernel_params, ego=False):
     return ce + 5e-4 * l2
 
 
-# ---- torch path: GraphGym's GNN with the 'stack' stage --------------------------------------
+# ---- torch path: GraphGym's GNN, module for module ------------------------------------------
+# The module tree (attribute names, nesting, which layers carry a bias) is the reference's, so that its state dicts load
+# with strict=True: tests/test_reference_checkpoint.py loads the two trained gcnidconv checkpoints the reference holds
+# (run/results/node*/1/ckpt/999.ckpt -> tests/golden/ref_ckpt_*.npz) into this class and into nothing else.
+#
+#   pre_mp.Layer_{i}.layer.model.weight            GeneralMultiLayer('linear', ...)      layer.py:50-67, gnn.py:23-25
+#   pre_mp.Layer_{i}.post_layer.0.*                BatchNorm1d of GeneralLayer           layer.py:26-35
+#   mp.layer{i}.layer.model.{weight,weight_id}     GNNStackStage -> GeneralLayer -> conv  gnn.py:65-74, idconv.py:396-404
+#   post_mp.layer_post_mp.model.{j}...             GNNNodeHead / GNNGraphHead -> MLP      head.py:19-37,96-119, layer.py:107-132
 class GeneralLayer(nn.Module):
     """graphgym/models/layer.py:16-47"""
 
@@ -118,59 +127,161 @@ class GeneralLayer(nn.Module):
 
     def forward(self, batch):
         batch = self.layer(batch)
+        if isinstance(batch, torch.Tensor):                      # layer.py:39-42 (the head's MLP passes tensors)
+            batch = self.post_layer(batch)
+            return F.normalize(batch, p=2, dim=1) if self.has_l2norm else batch
         batch.node_feature = self.post_layer(batch.node_feature)
         if self.has_l2norm:
             batch.node_feature = F.normalize(batch.node_feature, p=2, dim=1)
         return batch
 
 
-class _LinearLayer(nn.Module):
-    """graphgym/models/layer.py:70-82 ('linear' key)"""
+class GeneralMultiLayer(nn.Module):
+    """graphgym/models/layer.py:50-67: children named Layer_{i}"""
+
+    def __init__(self, name, num_layers, dim_in, dim_out, dim_inner=None, final_act=True, **kwargs):
+        super().__init__()
+        dim_inner = dim_in if dim_inner is None else dim_inner
+        for i in range(num_layers):
+            d_in = dim_in if i == 0 else dim_inner
+            d_out = dim_out if i == num_layers - 1 else dim_inner
+            has_act = final_act if i == num_layers - 1 else True
+            self.add_module('Layer_{}'.format(i), GeneralLayer(name, d_in, d_out, has_act, **kwargs))
+
+    def forward(self, batch):
+        for layer in self.children():
+            batch = layer(batch)
+        return batch
+
+
+class Linear(nn.Module):
+    """graphgym/models/layer.py:70-82 (the 'linear' key): the nn.Linear sits under `.model`"""
 
     def __init__(self, dim_in, dim_out, bias=False, **kwargs):
         super().__init__()
-        self.model = nn.Linear(dim_in, dim_out, bias=bias)
+        self.model = mpnn.Linear(dim_in, dim_out, bias=bias)     # nn.Linear's parameters and state dict, engine kernels
 
     def forward(self, batch):
+        if isinstance(batch, torch.Tensor):
+            return self.model(batch)
         batch.node_feature = self.model(batch.node_feature)
         return batch
 
 
-layer_dict.setdefault("linear", _LinearLayer)
+layer_dict.setdefault("linear", Linear)
 
 
-class GNNStack(nn.Module):
-    """gnn.py:123-168 with stage_type='stack' and the node head (head.py:19-37)"""
+class MLP(nn.Module):
+    """graphgym/models/layer.py:107-132: model = Sequential([GeneralMultiLayer('linear', n - 1), Linear]) or
+    Sequential([Linear]) for n <= 1"""
 
-    def __init__(self, dim_in, dim_out):
+    def __init__(self, dim_in, dim_out, bias=True, dim_inner=None, num_layers=2, **kwargs):
         super().__init__()
-        d = dim_in
-        mods = []
-        for _ in range(cfg.gnn.layers_pre_mp):
-            mods.append(GeneralLayer("linear", d, cfg.gnn.dim_inner))
-            d = cfg.gnn.dim_inner
-        self.pre_mp = nn.Sequential(*mods)
-        self.mp = nn.ModuleList()
-        for i in range(cfg.gnn.layers_mp):
-            self.mp.append(GeneralLayer(cfg.gnn.layer_type, d if i == 0 else cfg.gnn.dim_inner, cfg.gnn.dim_inner))
-        d = cfg.gnn.dim_inner if cfg.gnn.layers_mp > 0 else d
-        post = []
-        for _ in range(max(cfg.gnn.layers_post_mp, 1) - 1):
-            post.append(GeneralLayer("linear", d, d))
-        self.post_mp = nn.Sequential(*post)
-        self.out = nn.Linear(d, dim_out, bias=True)
+        dim_inner = dim_in if dim_inner is None else dim_inner
+        layers = []
+        if num_layers > 1:
+            layers.append(GeneralMultiLayer('linear', num_layers - 1, dim_in, dim_inner, dim_inner, final_act=True))
+            layers.append(Linear(dim_inner, dim_out, bias))
+        else:
+            layers.append(Linear(dim_in, dim_out, bias))
+        self.model = nn.Sequential(*layers)
 
     def forward(self, batch):
-        batch = self.pre_mp(batch)
-        for layer in self.mp:
+        if isinstance(batch, torch.Tensor):
+            return self.model(batch)
+        batch.node_feature = self.model(batch.node_feature)
+        return batch
+
+
+def GNNLayer(dim_in, dim_out, has_act=True):       # gnn.py:19-20
+    return GeneralLayer(cfg.gnn.layer_type, dim_in, dim_out, has_act)
+
+
+def GNNPreMP(dim_in, dim_out):                     # gnn.py:23-25
+    return GeneralMultiLayer('linear', cfg.gnn.layers_pre_mp, dim_in, dim_out, dim_inner=dim_out, final_act=True)
+
+
+class GNNStackStage(nn.Module):
+    """graphgym/models/gnn.py:65-81: children named layer{i}; row L2-normalisation behind the last one"""
+
+    def __init__(self, dim_in, dim_out, num_layers):
+        super().__init__()
+        for i in range(num_layers):
+            self.add_module('layer{}'.format(i), GNNLayer(dim_in if i == 0 else dim_out, dim_out))
+        self.dim_out = dim_out
+
+    def forward(self, batch):
+        for layer in self.children():
             batch = layer(batch)
         if cfg.gnn.l2norm:
             batch.node_feature = F.normalize(batch.node_feature, p=2, dim=-1)
-        batch = self.post_mp(batch)
-        pred = self.out(batch.node_feature)
+        return batch
+
+
+class GNNNodeHead(nn.Module):
+    """graphgym/models/head.py:19-37"""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.layer_post_mp = MLP(dim_in, dim_out, num_layers=cfg.gnn.layers_post_mp, bias=True)
+
+    def _apply_index(self, batch):
         idx = batch.node_label_index
-        label = batch.node_label if idx.shape[0] == batch.node_label.shape[0] else batch.node_label[idx]
-        return pred[idx], label
+        if idx.shape[0] == batch.node_label.shape[0]:
+            return batch.node_feature[idx], batch.node_label
+        return batch.node_feature[idx], batch.node_label[idx]
+
+    def forward(self, batch):
+        batch = self.layer_post_mp(batch)
+        return self._apply_index(batch)
+
+
+class GNNGraphHead(nn.Module):
+    """graphgym/models/head.py:96-119: pool (ego batches: the centre rows only, pooling.py:12-17), then the MLP"""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        from .pooling import pooling_dict
+        self.layer_post_mp = MLP(dim_in, dim_out, num_layers=cfg.gnn.layers_post_mp, bias=True)
+        self.pooling_fun = pooling_dict[cfg.model.graph_pooling]
+
+    def forward(self, batch):
+        if cfg.dataset.transform == 'ego':
+            graph_emb = self.pooling_fun(batch.node_feature, batch.batch, batch.node_id_index)
+        else:
+            graph_emb = self.pooling_fun(batch.node_feature, batch.batch)
+        batch.graph_feature = self.layer_post_mp(graph_emb)
+        return batch.graph_feature, batch.graph_label
+
+
+head_dict = {'node': GNNNodeHead, 'graph': GNNGraphHead}     # head.py:122-127 ('edge' / 'link_pred' are off the path)
+
+
+class GNN(nn.Module):
+    """graphgym/models/gnn.py:123-168 with stage_type 'stack' (the skip stages concatenate / add around the same
+    layers and are not on the path the BASELINE configs drive).  The feature-augmentation `preprocess` module of the
+    reference holds no parameters and is outside the path (SURVEY.md §2 #11): inputs arrive already assembled."""
+
+    def __init__(self, dim_in, dim_out, **kwargs):
+        super().__init__()
+        if getattr(cfg.gnn, "stage_type", "stack") != "stack":
+            raise ValueError("harness.GNN restates GNNStackStage only (cfg.gnn.stage_type = 'stack')")
+        d_in = dim_in
+        if cfg.gnn.layers_pre_mp > 0:
+            self.pre_mp = GNNPreMP(d_in, cfg.gnn.dim_inner)
+            d_in = cfg.gnn.dim_inner
+        if cfg.gnn.layers_mp > 0:
+            self.mp = GNNStackStage(dim_in=d_in, dim_out=cfg.gnn.dim_inner, num_layers=cfg.gnn.layers_mp)
+            d_in = self.mp.dim_out
+        self.post_mp = head_dict[getattr(cfg.dataset, "task", "node")](dim_in=d_in, dim_out=dim_out)
+
+    def forward(self, batch):
+        for module in self.children():
+            batch = module(batch)
+        return batch
+
+
+GNNStack = GNN      # the name rounds 1-2 used
 
 
 def train_step(model, optimizer, forward_loss, bucket=None):

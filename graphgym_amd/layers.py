@@ -377,12 +377,28 @@ class GINIDConvLayer(nn.Module):
         else:
             self.register_buffer('eps', torch.Tensor([eps]))
         self.train_eps = train_eps
+        self._eps_host = float(eps)
 
     _loops = "remove"
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # a loaded state_dict may carry another eps than the constructor's: refresh the host copy HERE (the tensor in
+        # the state dict is usually still on the host), so that forward never reads the device buffer back
+        t = state_dict.get(prefix + 'eps')
+        if t is not None and not self.train_eps:
+            self._eps_host = float(t)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def _eps_value(self):
-        # the registered buffer (a loaded state_dict may carry another eps than the constructor's)
-        return float(self.eps)
+        """eps of the fixed-eps form as a Python float, WITHOUT a device read (a `float(self.eps)` per forward is a host
+        synchronisation per layer call and cannot be captured into a HIP graph).  The buffer `eps` stays the
+        state-dict entry (idconv.py:361); the host copy follows the constructor and load_state_dict.  Code that
+        rewrites the buffer in place calls `sync_eps()` afterwards."""
+        return self._eps_host
+
+    def sync_eps(self):
+        self._eps_host = float(self.eps)
+        return self._eps_host
 
     def _combine(self, g, x):
         # (1 + eps) * x + sum_j x_j ; with a constant eps the self term rides in the aggregation's epilogue

@@ -123,6 +123,17 @@ register_autograd("mp::bn_act", _bn_backward, setup_context=_bn_setup)
 
 
 # ---- softmax cross-entropy over the labelled rows (graphgym/loss.py:53-68, 20-37) -------------------------------
+def _check_ce_shapes(z, y, idx):
+    """host-side shape contract (no device read): one label per selected row.  Label VALUES are checked on the device:
+    a label outside [0, C) or an index outside the logit matrix is never dereferenced and turns the loss into NaN."""
+    if z.dim() != 2:
+        raise ValueError(f"logits must be [n_rows, C], got {tuple(z.shape)}")
+    if idx is not None and idx.numel() != y.numel():
+        raise ValueError(f"index selects {idx.numel()} rows but there are {y.numel()} labels")
+    if idx is None and y.numel() > z.size(0):
+        raise ValueError(f"{y.numel()} labels for {z.size(0)} rows of logits")
+
+
 @custom_op("mp::softmax_ce_rows_raw", mutates_args=(), device_types="cuda")
 def _op_ce_rows_raw(logits: Tensor, labels: Tensor, index: Optional[Tensor]) -> Tensor:
     _require_hip(logits, "logits")
@@ -130,10 +141,11 @@ def _op_ce_rows_raw(logits: Tensor, labels: Tensor, index: Optional[Tensor]) -> 
     y = labels.to(torch.int64).contiguous()
     idx = None if index is None else index.to(torch.int64).contiguous()
     n_sel = y.numel()
+    _check_ce_shapes(z, y, idx)
     out = torch.empty(n_sel, dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
-        check(lib().mp_softmax_ce_rows_f32(ptr(z), z.stride(0), ptr(y), ptr(idx), n_sel, z.size(1), ptr(out), _stream()),
-              "mp_softmax_ce_rows_f32")
+        check(lib().mp_softmax_ce_rows_f32(ptr(z), z.stride(0), z.size(0), ptr(y), ptr(idx), n_sel, z.size(1), ptr(out),
+                                           _stream()), "mp_softmax_ce_rows_f32")
     return out
 
 
@@ -148,9 +160,12 @@ def _op_ce_bwd_raw(logits: Tensor, labels: Tensor, index: Optional[Tensor], gsca
     y = labels.to(torch.int64).contiguous()
     idx = None if index is None else index.to(torch.int64).contiguous()
     g = gscale.to(torch.float32).reshape(1).contiguous()
-    d = torch.zeros_like(z) if idx is not None else torch.empty_like(z)
+    _check_ce_shapes(z, y, idx)
+    # with an index the rows accumulate onto zeros (a row listed twice gets both terms); without one every row of the
+    # first n_sel is written once and the rest must still be zero
+    d = torch.zeros_like(z) if (idx is not None or y.numel() < z.size(0)) else torch.empty_like(z)
     with torch.cuda.device(z.device):
-        check(lib().mp_softmax_ce_bwd_f32(ptr(z), z.stride(0), ptr(y), ptr(idx), y.numel(), z.size(1), ptr(g),
+        check(lib().mp_softmax_ce_bwd_f32(ptr(z), z.stride(0), z.size(0), ptr(y), ptr(idx), y.numel(), z.size(1), ptr(g),
                                           float(inv_n), ptr(d), d.stride(0), _stream()), "mp_softmax_ce_bwd_f32")
     return d
 

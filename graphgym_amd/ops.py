@@ -169,27 +169,17 @@ def agg_dense_supported(g, x, W):
             and g.nnz > 0 and g.max_row_entries() <= FUSED_MAX_ROW)
 
 
-BF16X3_MIN_ROWS = 1 << 19   # below this the split of W (a few small launches per call) costs more than the shorter MFMA phase saves
-_split_cache = {}
+BF16X3_MIN_ROWS = 1 << 19   # below this the split of W (one small launch per call) costs more than the shorter MFMA phase saves
 
 
 def _split_bf16_t(W):
     """W [F, d] fp32 -> [3, F / 8, d, 8] bf16: W split three ways, plane s = bf16(W - sum of the planes before it)
     (24 mantissa bits in all), in the layout the bf16x3 product of mp_agg_dense_f32 loads (a lane's 8 k-values of a
-    column contiguous, neighbouring columns neighbours); cached per weight version"""
-    key = (W.data_ptr(), tuple(W.shape), W._version)
-    hit = _split_cache.get("k")
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    Wf = W.detach().float()
-    F, d = Wf.shape
-    w0 = Wf.to(torch.bfloat16)
-    r1 = Wf - w0.float()
-    w1 = r1.to(torch.bfloat16)
-    w2 = (r1 - w1.float()).to(torch.bfloat16)
-    sp = torch.stack([w0, w1, w2]).view(3, F // 8, 8, d).permute(0, 1, 3, 2).contiguous()
-    _split_cache["k"] = (key, sp, W)        # holding W keeps its address from being reused under a stale key
-    return sp
+    column contiguous, neighbouring columns neighbours).  Split afresh on every call (mp_split_w_bf16x3, one ~5 us
+    launch): nothing observable from Python says W is unchanged — `w.data.uniform_()` (the reference's own
+    reset_parameters idiom, idconv.py:125-128) rewrites a weight without touching `_version`, and a cached split
+    would then multiply by the old weights silently."""
+    return _split_w(W)
 
 
 def _raw_agg_dense(g, x, W, bias=None, relu=False, S=None, self_scale=0.0, want_P=False, reduce=_lib.SUM,

@@ -389,18 +389,22 @@ int mp_dense_wgrad_relu_f32(const float* P, int64_t ldp, const float* G, int64_t
  * Loss of the training step that drives the path: softmax cross-entropy  *
  * over the labelled rows (graphgym/loss.py:53-68 masked_logits =          *
  * logits[node_label_index], mean softmax-CE; loss.py:20-37 torch path).   *
- * index [n_sel] int64 selects rows of logits (NULL = rows 0..n_sel-1);   *
- * labels [n_sel] int64 in [0, C).                                         *
+ * logits [n_rows, C]; index [n_sel] int64 selects rows of logits (NULL  *
+ * = rows 0..n_sel-1); labels [n_sel] int64 in [0, C).  A label outside  *
+ * [0, C) (torch's ignore_index is NOT implemented) or an index outside  *
+ * [0, n_rows) is never dereferenced: that row's loss is NaN (so the mean *
+ * is NaN) and it receives no gradient.                                   *
  *   rows:  row_loss[k] = logsumexp(z_i) - z_i[y_k]                        *
- *   bwd:   dlogits[i, :] = (softmax(z_i) - onehot(y_k)) * gscale[0] * inv_n *
- *          (gscale: device scalar, the upstream gradient; rows not in     *
- *          index are left untouched — zero dlogits first for a subset)    *
+ *   bwd:   dlogits[i, :] (+)= (softmax(z_i) - onehot(y_k)) * gscale[0] * inv_n *
+ *          (gscale: device scalar, the upstream gradient).  With an index *
+ *          the caller zeroes dlogits first and rows ACCUMULATE, so a row  *
+ *          listed k times gets k terms, like F.cross_entropy(logits[index]) *
  * ------------------------------------------------------------------ */
-int mp_softmax_ce_rows_f32(const float* logits, int64_t ld, const int64_t* labels, const int64_t* index,
-                           int64_t n_sel, int32_t C, float* row_loss, mp_stream_t stream);
-int mp_softmax_ce_bwd_f32(const float* logits, int64_t ld, const int64_t* labels, const int64_t* index,
-                          int64_t n_sel, int32_t C, const float* gscale, float inv_n, float* dlogits, int64_t ldd,
-                          mp_stream_t stream);
+int mp_softmax_ce_rows_f32(const float* logits, int64_t ld, int64_t n_rows, const int64_t* labels,
+                           const int64_t* index, int64_t n_sel, int32_t C, float* row_loss, mp_stream_t stream);
+int mp_softmax_ce_bwd_f32(const float* logits, int64_t ld, int64_t n_rows, const int64_t* labels,
+                          const int64_t* index, int64_t n_sel, int32_t C, const float* gscale, float inv_n,
+                          float* dlogits, int64_t ldd, mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * Identity-row update (K10): H[id[k], :] += U[k, :]                   *

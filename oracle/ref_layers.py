@@ -323,3 +323,43 @@ def compute_identity(edge_index, n, k):
         power = power @ adj
         diag_all.append(torch.diag(power))
     return torch.stack(diag_all, dim=1)
+
+
+# ------------- GraphGym's assembled GNN in eval mode, driven by a reference state dict ------------- #
+def graphgym_gnn_eval(state, x, edge_index, node_id_index, *, layers_pre_mp, layers_mp, bn_eps=1e-5, l2norm=True,
+                      task="node", ego=True, node_label_index=None, batch=None, num_graphs=None):
+    """GNN.forward (graphgym/models/gnn.py:165-168) in eval mode for layer_type 'gcnidconv', stage 'stack',
+    layers_post_mp = 1, evaluated from a state dict WITH THE REFERENCE'S OWN KEYS (the checkpoints under
+    run/results/node*/1/ckpt hold exactly these):
+
+        pre_mp.Layer_i      GeneralLayer('linear'): nn.Linear without bias -> BatchNorm1d(eval) -> ReLU   layer.py:16-47,70-82
+        mp.layer{i}         GeneralLayer('gcnidconv'): GCNIDConvLayer (idconv.py:150-177, no bias under BN) -> BN -> ReLU
+        (stage end)         F.normalize(p=2, dim=-1) if cfg.gnn.l2norm                                     gnn.py:79-80
+        post_mp             node:  Linear(+bias) on all rows, then rows node_label_index                   head.py:19-37
+                            graph: global_add_pool over the centre rows of each graph (transform 'ego':
+                                   index_select by node_id_index first), then Linear(+bias)                head.py:96-119,
+                                                                                                            pooling.py:12-17
+    All arithmetic in the dtype of `x` (tests pass float64)."""
+    t = lambda k: torch.as_tensor(state[k]).to(x.dtype)
+
+    def bn_relu(h, prefix):
+        h = (h - t(prefix + ".running_mean")) / torch.sqrt(t(prefix + ".running_var") + bn_eps)
+        return torch.relu(h * t(prefix + ".weight") + t(prefix + ".bias"))
+
+    h = x
+    for i in range(layers_pre_mp):
+        h = bn_relu(h @ t(f"pre_mp.Layer_{i}.layer.model.weight").t(), f"pre_mp.Layer_{i}.post_layer.0")
+    for i in range(layers_mp):
+        h = gcnid_conv(h, edge_index, node_id_index, t(f"mp.layer{i}.layer.model.weight"),
+                       t(f"mp.layer{i}.layer.model.weight_id"), bias=None)
+        h = bn_relu(h, f"mp.layer{i}.post_layer.0")
+    if l2norm:
+        h = F.normalize(h, p=2, dim=-1)
+    Wp, bp = t("post_mp.layer_post_mp.model.0.model.weight"), t("post_mp.layer_post_mp.model.0.model.bias")
+    if task == "node":
+        return (h @ Wp.t() + bp)[node_label_index]
+    if ego:
+        h, batch = h.index_select(0, node_id_index), batch.index_select(0, node_id_index)
+    size = int(batch.max()) + 1 if num_graphs is None else num_graphs
+    emb = torch.zeros(size, h.size(1), dtype=h.dtype).index_add_(0, batch, h)      # scatter(reduce='add')
+    return emb @ Wp.t() + bp

@@ -29,3 +29,24 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return load
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """how often the fp32-oracle allowance of tests/_tol.py was the binding term: gpurun_out/tol_stats.json"""
+    try:
+        import json
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _tol
+        if not _tol.STATS:
+            return
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        calls = len(_tol.STATS)
+        rows = sum(s["rows"] for s in _tol.STATS)
+        needed = sum(s["needed_ref32"] for s in _tol.STATS)
+        worst = sorted((s for s in _tol.STATS if s["needed_ref32"]), key=lambda s: -s["frac"])[:40]
+        with open(os.path.join(out, "tol_stats.json"), "w") as f:
+            json.dump({"calls": calls, "calls_needing_ref32": sum(1 for s in _tol.STATS if s["needed_ref32"]),
+                       "rows": rows, "rows_needing_ref32": needed, "largest_fractions": worst}, f, indent=1)
+    except Exception:
+        pass

@@ -63,9 +63,10 @@ def _graph(n, gen):
 
 
 def _oracle_general_layer(kind, x, ei, ids, W, Wid, bias, bn, training, has_l2norm):
-    """conv (oracle/ref_layers) -> BatchNorm1d -> ReLU -> F.normalize, float64"""
+    """conv (oracle/ref_layers) -> BatchNorm1d -> ReLU -> F.normalize, in the dtype of x (float64 / float32)"""
     from oracle import ref_layers as RL
-    torch.set_default_dtype(torch.float64)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(x.dtype)
     try:
         if kind == "gcnconv":
             h = RL.pyg_gcn_conv(x, ei, W, bias)
@@ -81,7 +82,7 @@ def _oracle_general_layer(kind, x, ei, ids, W, Wid, bias, bn, training, has_l2no
         h = torch.relu(h)
         return F.normalize(h, p=2, dim=1) if has_l2norm else h
     finally:
-        torch.set_default_dtype(torch.float32)
+        torch.set_default_dtype(prev)
 
 
 @pytest.mark.gpu
@@ -123,13 +124,21 @@ def test_accelerated_layer_matches_the_oracle_train_and_eval(dev, kind, has_bn, 
     out = layer(batch).node_feature
     up = torch.randn(n, d, generator=gen)
     out.backward(up.to(dev))
-    xr = x.double().requires_grad_(True)
-    Wr = W.clone().requires_grad_(True)
-    ref = _oracle_general_layer(kind, xr, ei, ids, Wr, Wid, bias, bn_state(), True, has_l2norm)
-    ref.backward(up.double())
-    assert_close_rows(out, ref.detach(), 1e-5, what="train out")
-    assert_close_rows(xin.grad, xr.grad, 2e-5, what="train dx")
-    assert_close_all(conv.weight.grad, Wr.grad, 2e-5, what="train dW")
+    from _tol import both
+    state = bn_state()
+
+    def ref_fn(c):
+        xr = c(x).clone().requires_grad_(True)
+        Wr = c(W.float()).clone().requires_grad_(True)
+        cc = lambda t: None if t is None else c(t.float())
+        bn = None if state is None else tuple(cc(t) for t in state[:4]) + (state[4],)
+        ref = _oracle_general_layer(kind, xr, ei, ids, Wr, cc(Wid), cc(bias), bn, True, has_l2norm)
+        ref.backward(c(up))
+        return ref.detach(), xr.grad, Wr.grad
+    r64, r32 = both(ref_fn)
+    assert_close_rows(out, r64[0], 1e-5, ref32=r32[0], what="train out")
+    assert_close_rows(xin.grad, r64[1], 1e-5, ref32=r32[1], what="train dx")
+    assert_close_all(conv.weight.grad, r64[2], 1e-5, ref32=r32[2], what="train dW")
     if has_bn:
         b = layer.post_layer[0]
         assert int(b.num_batches_tracked) == 1 and float((b.running_mean.abs()).max()) > 0

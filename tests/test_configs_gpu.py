@@ -341,3 +341,176 @@ def test_c5_d512_aggregation_and_two_branch_at_10m(dev, big_graph):
     q32 = torch.zeros(rows.numel(), d).index_add_(0, seg[keep], val[keep, None] * xg[keep])
     assert_close_rows(Q[rows], q64, 1e-5, ref32=q32, what="C5 identity branch Q, d=512")
     assert int((Q[rows].abs().sum(1) > 0).sum()) > 0             # the sample does touch identity neighbours
+
+
+# ------------------------------------------------------------------------------------------ C5 as the product dispatches it
+def test_c5_one_kernel_layer_d512_at_10m(dev, big_graph):
+    """config C5 on ITS product path: at d = 512 the layers do not call ops.spmm — Tfg-idgin's head runs
+    (1 + eps) x + sum_j x_j -> Dense(512, relu) as ONE launch of mp_agg_dense_f32 with two K halves (fused.hip,
+    KH == 2; TfgIDLayer.py:143-167, main_zd.py:209-227), and an ID-GCN layer runs mp::agg_dense_id.  Both at
+    N = 10^7, F = 512, 520 sampled rows incl. the hubs against the oracle's aggregate in float64."""
+    from graphgym_amd import ops
+    G0, n, d = big_graph, N_BIG, 512
+    gen = torch.Generator(device=dev).manual_seed(17)
+    x = torch.rand(n, d, device=dev, generator=gen) * 2 - 1
+    rows = _sample_rows(G0, gen)
+    xs = x[rows].cpu()
+    s64, s32, _ = _sampled_aggregate(G0, x, rows, "sum")
+    b = torch.rand(d, device=dev, generator=gen) - 0.5
+    for d_out in (512, 256):
+        W = (torch.rand(d, d_out, device=dev, generator=gen) - 0.5) * (2.0 / d ** 0.5)
+        assert ops.agg_dense_supported(G0, x, W)                             # the one-kernel path is what runs
+        with torch.no_grad():
+            out = ops.agg_dense(G0, x, W, bias=b[:d_out], relu=True, self_scale=1.0)
+        ref64 = torch.relu((s64 + xs.double()) @ W.cpu().double() + b[:d_out].cpu().double())
+        ref32 = torch.relu((s32 + xs) @ W.cpu() + b[:d_out].cpu())
+        assert_close_rows(out[rows], ref64, 1e-5, ref32=ref32, what=f"C5 one-kernel GIN head 512 -> {d_out}")
+        del out
+    # the ID-GCN layer at d = 512: act(A (x W + S x W_id) + b), GCN-normalised operator (gcn_id, TfgIDLayer.py:510-523)
+    G = G0.gcn_norm("row")
+    ids = torch.randperm(n, device=dev, generator=gen)[: n // 100]
+    ids = torch.cat([torch.arange(0, 4, device=dev), ids[ids >= 4]])
+    W = (torch.rand(d, d, device=dev, generator=gen) - 0.5) * (2.0 / d ** 0.5)
+    Wid = (torch.rand(d, d, device=dev, generator=gen) - 0.5) * (2.0 / d ** 0.5)
+    with torch.no_grad():
+        out = ops.agg_dense_id(G, x, W, Wid, ids, bias=b, relu=True)
+    assert out is not None
+    p64, p32, _ = _sampled_aggregate(G, x, rows, "sum")
+    is_id = torch.zeros(n, dtype=torch.bool, device=dev)
+    is_id[ids] = True
+    seg, col, val, _ = _sampled_entries(G, rows)
+    keep = is_id[col].cpu()
+    xg = x[col].cpu()
+    q64 = torch.zeros(rows.numel(), d, dtype=torch.float64).index_add_(0, seg[keep], val[keep, None].double() * xg[keep].double())
+    q32 = torch.zeros(rows.numel(), d).index_add_(0, seg[keep], val[keep, None] * xg[keep])
+    ref64 = torch.relu(p64 @ W.cpu().double() + q64 @ Wid.cpu().double() + b.cpu().double())
+    ref32 = torch.relu(p32 @ W.cpu() + q32 @ Wid.cpu() + b.cpu())
+    assert int((q64.abs().sum(1) > 0).sum()) > 0
+    assert_close_rows(out[rows], ref64, 1e-5, ref32=ref32, what="C5 ID-GCN layer (agg_dense_id), d = 512")
+
+
+def test_c5_idgin_layer_d512_at_10m(dev, big_graph):
+    """config C5's layer itself at N = 10^7, d = 512, as harness / the plugin build it: IDGIN(mlp, mlp_id) with the keras
+    MLPs Dense(512, relu) -> Dense(512) -> BatchNorm -> relu (main_zd.py:214-225), eval mode (BatchNorm on its running
+    statistics is row-local, so sampled rows can be checked): the one-kernel head + _id_mlp_rows — the identity nodes'
+    rows of h re-aggregated over their own in-edges (TfgIDLayer.py:157-165)"""
+    from graphgym_amd import harness as H, layers as L
+    G0, n, d = big_graph, N_BIG, 512
+    gen = torch.Generator(device=dev).manual_seed(19)
+    x = torch.rand(n, d, device=dev, generator=gen) * 2 - 1
+    rows = _sample_rows(G0, gen)
+    ids = torch.randperm(n, device=dev, generator=gen)[: n // 100]
+    ids = torch.unique(torch.cat([rows[::2], ids]))                      # half of the sampled rows are identity nodes
+    torch.manual_seed(5)
+    layer = L.IDGIN(H._keras_gin_mlp(d, d), H._keras_gin_mlp(d, d)).to(dev).eval()
+    for mlp in (layer.mlp_model, layer.mlp_id):                        # non-trivial running statistics / affine
+        bn = mlp[3]
+        with torch.no_grad():
+            bn.running_mean.copy_(torch.rand(d, generator=torch.Generator().manual_seed(1)) - 0.5)
+            bn.running_var.copy_(torch.rand(d, generator=torch.Generator().manual_seed(2)) + 0.5)
+            bn.weight.copy_(torch.rand(d, generator=torch.Generator().manual_seed(3)) + 0.5)
+            bn.bias.copy_(torch.rand(d, generator=torch.Generator().manual_seed(4)) - 0.5)
+    # the layer gets an edge_index like any caller's (and builds / caches its own CSR on the holder)
+    holder = H.Batch()
+    ei = torch.stack([G0.row_ids().long(), G0.col.long()])             # TF convention: edge_index[0] = destination row
+    with torch.no_grad():
+        out = layer([x, ei, ids], training=False, holder=holder)
+    del ei
+    s64, s32, _ = _sampled_aggregate(G0, x, rows, "sum")
+    xs = x[rows].cpu()
+    in_id = torch.isin(rows, ids).cpu()
+
+    def run(dtype, agg):
+        h = (agg + xs.to(dtype))
+        outs = []
+        for mlp in (layer.mlp_model, layer.mlp_id):
+            p = lambda t: t.detach().cpu().to(dtype)
+            z = torch.relu(h @ p(mlp[0].weight).t() + p(mlp[0].bias)) @ p(mlp[2].weight).t() + p(mlp[2].bias)
+            bn = mlp[3]
+            z = (z - p(bn.running_mean)) / torch.sqrt(p(bn.running_var) + bn.eps) * p(bn.weight) + p(bn.bias)
+            outs.append(torch.relu(z))
+        return outs[0] + outs[1] * in_id[:, None].to(dtype)
+    assert int(in_id.sum()) >= 200
+    assert_close_rows(out[rows], run(torch.float64, s64), 1e-5, ref32=run(torch.float32, s32),
+                      what="C5 IDGIN layer, d = 512, N = 10^7")
+
+
+def _oracle_tfg_gin_model(params, buffers, x, ei, ids, label_index, labels, dtype, masks, n_layers, with_id):
+    """main_zd.py:209-243 (IDGINModel: layers_mp x IDGIN(mlp, mlp_id) -> Flatten -> Dense(256, relu) -> Dense(labels)),
+    training mode (BatchNormalization on batch statistics, eps 1e-3), with the loss of graphgym/loss.py:53-68, on the
+    CPU in `dtype`; ReLUs follow the engine's activation patterns `masks[name]` (see _oracle_tfg_gcn_model)."""
+    torch.set_default_dtype(dtype)
+    try:
+        P = {k: v.detach().cpu().to(dtype).clone().requires_grad_(True) for k, v in params.items()}
+
+        def relu_like_engine(pre, name):
+            mask = masks[name]
+            off = (pre.detach() > 0) != mask
+            if bool(off.any()):
+                worst = float(pre.detach().abs()[off].max())
+                assert worst <= 1e-5 * float(pre.detach().abs().max()), \
+                    f"{name}: activation pattern differs at an input of magnitude {worst:.3e}"
+            return pre * mask.to(dtype)
+
+        def mlp_fn(prefix):
+            def f(h):
+                z = relu_like_engine(h @ P[prefix + ".0.weight"].t() + P[prefix + ".0.bias"], prefix + ".1")
+                z = z @ P[prefix + ".2.weight"].t() + P[prefix + ".2.bias"]
+                z = F.batch_norm(z, None, None, P[prefix + ".3.weight"], P[prefix + ".3.bias"], True, 0.01, 1e-3)
+                return relu_like_engine(z, prefix + ".3")
+            return f
+        h = x.detach().cpu().to(dtype)
+        for i in range(n_layers):
+            h = RL.idgin(h, ei, ids if with_id else None, mlp_fn(f"convs.{i}.mlp_model"),
+                         mlp_fn(f"convs.{i}.mlp_id") if with_id else None)
+        pre = h @ P["mlp.1.weight"].t() + P["mlp.1.bias"]
+        logits = relu_like_engine(pre, "mlp.2") @ P["mlp.3.weight"].t() + P["mlp.3.bias"]
+        ce = F.cross_entropy(logits[label_index], labels)
+        kern = [P[k] for k in P if k.endswith(".weight") and P[k].dim() == 2]
+        loss = ce + 5e-4 * sum((p * p).sum() / 2 for p in kern)
+        loss.backward()
+        return logits.detach(), loss.detach(), {k: v.grad for k, v in P.items()}
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_c5_idgin_tf_model_d512_on_ego_batch_of_the_10m_graph(dev, big_graph):
+    """config C5, model level: idgin_tf = 3 x IDGIN with the keras MLPs, d = 512 (main_zd.py:209-243), one training
+    step (logits, loss, every parameter gradient) on a radius-2 ego batch of the 10^7-node BA graph built by the GPU
+    batcher, against the oracle model in float64 / float32"""
+    from graphgym_amd import harness as H
+    from graphgym_amd.ego import ego_batch
+    d, classes, n_layers = 512, 10, 3
+    gen = torch.Generator(device=dev).manual_seed(23)
+    cen = torch.randint(1000, N_BIG, (96,), device=dev, generator=gen).unique()
+    ei, orig, ids, ego_of = ego_batch(big_graph, cen, 2)
+    n_b = orig.numel()
+    assert 5_000 <= n_b <= 600_000, n_b
+    x = (torch.rand(N_BIG, 8, device=dev, generator=gen) * 2 - 1)[orig]            # 8 input features -> d = 512
+    labels = torch.randint(0, classes, (ids.numel(),), device=dev, generator=gen)
+    ei_tf = torch.stack([ei[1], ei[0]])                                            # TF convention: row 0 = destination
+    torch.manual_seed(7)
+    model = H.TfgNodeModel("idgin", 8, d, classes, layers_mp=n_layers).to(dev).train()
+    acts = {}
+    hooks = []
+    for name, mod in model.named_modules():
+        leaf = name.split(".")[-1]
+        if (("mlp_model" in name or "mlp_id" in name) and leaf in ("1", "3")) or name == "mlp.2":
+            hooks.append(mod.register_forward_hook(lambda m, i, o, name=name: acts.__setitem__(name, o.detach())))
+    holder = H.Batch()
+    logits = model([x, ei_tf, ids], holder=holder)
+    for hk in hooks:
+        hk.remove()
+    assert len(acts) == 4 * n_layers + 1, sorted(acts)
+    masks = {k: (v > 0).cpu() for k, v in acts.items()}
+    loss = H.tfg_loss(logits, ids, labels, model.kernel_parameters())
+    loss.backward()
+    params = dict(model.named_parameters())
+    args = (x, ei_tf.cpu(), ids.cpu(), ids.cpu(), labels.cpu())
+    l64, loss64, g64 = _oracle_tfg_gin_model(params, None, *args, torch.float64, masks, n_layers, True)
+    l32, loss32, g32 = _oracle_tfg_gin_model(params, None, *args, torch.float32, masks, n_layers, True)
+    assert_close_rows(logits, l64, 1e-5, ref32=l32, what="idgin d=512 logits")
+    assert_close_all(loss.reshape(1), loss64.reshape(1), 1e-5, ref32=loss32.reshape(1), what="idgin d=512 loss")
+    for k, p in params.items():
+        assert p.grad is not None, k
+        assert_close_all(p.grad, g64[k], 1e-5, ref32=g32[k], what=f"idgin d=512 grad {k}")

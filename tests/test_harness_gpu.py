@@ -79,21 +79,28 @@ def test_idgcn_model_step_matches_oracle(dev):
     loss = H.tfg_loss(model(inputs, holder=batch), batch.node_label_index, batch.node_label,
                       model.kernel_parameters())
     loss.backward()
-    # oracle: the same model restated on the CPU (TfgIDLayer.py:478-525 + main_zd.py:65-74 + loss.py:53-68)
+    # oracle: the same model restated on the CPU (TfgIDLayer.py:478-525 + main_zd.py:65-74 + loss.py:53-68), in float64
+    # and in float32 (tests/_tol.py); a ReLU input within rounding of zero has no defined subgradient, so a handful of
+    # activations may legitimately differ — the model-level tests of test_configs_gpu.py pin the pattern; here the
+    # graph is small enough that the float32 oracle's own distance covers it
+    from _tol import both, close_all
     x, ei, ids = batch.node_feature.cpu(), batch.edge_index.cpu(), batch.node_id_index.cpu()
-    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
-    h = x
-    for i in range(3):
-        h = RL.gcn_id(h, ei, ids, None, P[f"convs.{i}.kernel"], P[f"convs.{i}.kernel_id"], P[f"convs.{i}.bias"], "relu")
-    h = torch.relu(h @ P["mlp.1.weight"].t() + P["mlp.1.bias"]) @ P["mlp.3.weight"].t() + P["mlp.3.bias"]
-    ce = torch.nn.functional.cross_entropy(h[batch.node_label_index.cpu()], batch.node_label.cpu())
-    kern = [P[k] for k in P if k.endswith("kernel") or k.endswith("kernel_id") or k.endswith(".weight")]
-    ref = ce + 5e-4 * sum((p * p).sum() / 2 for p in kern)
-    ref.backward()
-    assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+
+    def ref_fn(c):
+        P = {k: c(v.detach().cpu()).clone().requires_grad_(True) for k, v in model.named_parameters()}
+        h = c(x)
+        for i in range(3):
+            h = RL.gcn_id(h, ei, ids, None, P[f"convs.{i}.kernel"], P[f"convs.{i}.kernel_id"], P[f"convs.{i}.bias"], "relu")
+        h = torch.relu(h @ P["mlp.1.weight"].t() + P["mlp.1.bias"]) @ P["mlp.3.weight"].t() + P["mlp.3.bias"]
+        ce = torch.nn.functional.cross_entropy(h[batch.node_label_index.cpu()], batch.node_label.cpu())
+        kern = [P[k] for k in P if k.endswith("kernel") or k.endswith("kernel_id") or k.endswith(".weight")]
+        ref = ce + 5e-4 * sum((p * p).sum() / 2 for p in kern)
+        ref.backward()
+        return ref.detach().reshape(1), {k: v.grad for k, v in P.items()}
+    (l64, g64), (l32, g32) = both(ref_fn)
+    close_all(loss.reshape(1), (l64, l32), what="loss")
     for k, p in model.named_parameters():
-        g, gr = p.grad.cpu(), P[k].grad
-        assert float((g - gr).abs().max()) <= 1e-4 * max(1.0, float(gr.abs().max())), k
+        close_all(p.grad, (g64[k], g32[k]), what=f"grad {k}")
 
 
 def test_identity_branch_lifts_accuracy_like_the_reference(dev):
@@ -130,5 +137,8 @@ def test_hip_graph_replay_matches_eager_training(dev):
         else:
             step = H.GraphedTrainStep(model, opt, fl, warmup=3)          # 3 eager steps, then replays
             losses[mode] = [None] * 3 + [float(step()) for _ in range(10)]
+    # two float32 TRAINING TRAJECTORIES (13 Adam steps each), not an operator against its oracle: the captured step runs
+    # the same kernels, so the losses normally agree to the last bits; 1e-4 bounds the drift a reordered reduction in a
+    # library kernel under capture could introduce over the steps
     for a, b in zip(losses["eager"][3:], losses["graph"][3:]):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (losses["eager"], losses["graph"])

@@ -321,17 +321,18 @@ def test_generalconv_with_edge_features(dev, agg):
         xd, efd = x.to(dev).requires_grad_(True), ef.to(dev).requires_grad_(True)
         out = m(xd, ei.to(dev), edge_feature=efd)
         out.backward(up.to(dev))
-        torch.set_default_dtype(torch.float64)
-        try:
-            xr, efr = x.double().requires_grad_(True), ef.double().requires_grad_(True)
-            W, Ws, b = (p.detach().cpu().double().requires_grad_(True) for p in (m.weight, m.weight_self, m.bias))
+        from _tol import both
+
+        def ref_fn(c):
+            xr, efr = c(x).clone().requires_grad_(True), c(ef).clone().requires_grad_(True)
+            W, Ws, b = (c(p.detach().cpu()).clone().requires_grad_(True) for p in (m.weight, m.weight_self, m.bias))
             ref = RL.general_conv(xr, ei, W, Ws, b, agg=agg, edge_feature=efr)
-            ref.backward(up.double())
-        finally:
-            torch.set_default_dtype(torch.float32)
-        assert_close_rows(out, ref.detach(), 1e-5, what="out")
-        assert_close_rows(xd.grad, xr.grad, 2e-5, what="dx")
-        assert_close_rows(efd.grad, efr.grad, 1e-5, what="d edge_feature")
-        assert_close_all(m.weight.grad, W.grad, 2e-5, what="dW")
+            ref.backward(c(up))
+            return ref.detach(), xr.grad, efr.grad, W.grad
+        r64, r32 = both(ref_fn)
+        assert_close_rows(out, r64[0], 1e-5, ref32=r32[0], what="out")
+        assert_close_rows(xd.grad, r64[1], 1e-5, ref32=r32[1], what="dx")
+        assert_close_rows(efd.grad, r64[2], 1e-5, ref32=r32[2], what="d edge_feature")
+        assert_close_all(m.weight.grad, r64[3], 1e-5, ref32=r32[3], what="dW")
     finally:
         cfg.gnn.agg, cfg.gnn.normalize_adj, cfg.gnn.self_msg = old

@@ -1,28 +1,20 @@
 """Parity of the HIP path (through the C ABI: graphgym_amd.graph / ops -> libmpengine.so)
 against the CPU oracle and the committed golden vectors.
 
-Bars: integer / index work bit-exact; fp32 aggregation within 1e-5 (relative to the
-magnitude of the row being summed: |err| <= 1e-5 * max(1, max|ref|)), the tolerance
-BASELINE.json's north_star states.  The oracle is unpinned by the reference.
+Bars: integer / index work bit-exact; fp32 results within 1e-5 of EVERY OUTPUT ROW's own magnitude against a
+float64 evaluation of the oracle on the same fp32 inputs — tests/_tol.py, the one tolerance regime of the suite
+(`close(engine, both(lambda c: oracle(c(inputs))))`: the closure is evaluated in float64 and in the reference's
+float32; rows outside 1e-5 may use twice the float32 oracle's own distance from float64, and _tol polices how many do).
+The oracle is unpinned by the reference's numerics.
 """
 import numpy as np
 import pytest
 import torch
 
+from _tol import both, close, close_all
 from oracle import ref_ops as R
 
 pytestmark = pytest.mark.gpu
-
-
-def close(a, ref, tol=1e-5):
-    a = a.detach().cpu().double()
-    ref = ref.detach().cpu().double() if isinstance(ref, torch.Tensor) else torch.from_numpy(np.asarray(ref)).double()
-    assert a.shape == ref.shape, (a.shape, ref.shape)
-    if a.numel() == 0:
-        return
-    scale = max(1.0, float(ref.abs().max()))
-    err = float((a - ref).abs().max())
-    assert err <= tol * scale, f"max err {err:.3e} > {tol:.0e} * {scale:.3g}"
 
 
 def csr_reference(dst, src, N, w=None):
@@ -54,6 +46,77 @@ def test_csr_build_is_bit_exact(dev):
         rowptr2, col2, _, _ = csr_reference(ei[0].numpy(), ei[1].numpy(), N)
         assert (G2.rowptr.cpu().numpy() == rowptr2).all() and (G2.col.cpu().numpy() == col2).all()
         assert G2.val is None
+
+
+@pytest.mark.parametrize("n", [1_000_000, 10_000_000])
+def test_csr_and_transpose_index_exact_at_baseline_sizes(dev, n):
+    """north_star: "bit-exact edge indexing" — at the C2 / C4 sizes, against an INDEPENDENT device computation
+    (torch.sort / bincount / cumsum), not against the engine's own CSR: a mis-sorted or dropped entry anywhere in the
+    1.2 * 10^8-key rocPRIM sort -> rowptr -> emit -> transpose chain fails a torch.equal here.
+
+    Semantics pinned: row = destination (sparse_adj.py:91-97: unsorted_segment_sum over edge_index[0] in the TF
+    convention; PyG: aggregation at edge_index[1]), entries of a row ordered by (source, input position), loops
+    appended behind the input edges (sparse_adj.py:58-63 add_self_loop -> concat), and for the PyG policy
+    add_remaining_self_loops (idconv.py:140-141): an existing loop is dropped and re-added once with its weight."""
+    import graphgym_amd as ga
+    from graphgym_amd import graphgen
+    gen = torch.Generator(device=dev).manual_seed(n % 1000 + 3)
+    ei = graphgen.ba_edge_index(n, 5, seed=12345, device=dev)           # comes out sorted by (dst, src): shuffle it,
+    ei = ei[:, torch.randperm(ei.size(1), device=dev, generator=gen)]   # so that the sort has real work to do
+    # duplicates (a multigraph keeps them, in input order) and explicit self loops on distinct nodes
+    dup = ei[:, torch.randint(0, ei.size(1), (50_000,), device=dev, generator=gen)]
+    loops = torch.randperm(n, device=dev, generator=gen)[:30_000]
+    ei = torch.cat([ei, dup, torch.stack([loops, loops])], dim=1)
+    ei = ei[:, torch.randperm(ei.size(1), device=dev, generator=gen)]
+    E = ei.size(1)
+    w = torch.rand(E, device=dev, generator=gen) + 0.5
+    src, dst = ei[0], ei[1]
+    ar = torch.arange(n, device=dev)
+
+    def expect(s_in, d_in, w_in, eid_in):
+        key = d_in * n + s_in
+        skey, order = torch.sort(key, stable=True)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(d_in, minlength=n), 0)
+        return skey, order, rowptr, w_in[order], eid_in[order]
+
+    def check(G, s_in, d_in, w_in, eid_in, what):
+        skey, order, rowptr, wv, eid = expect(s_in, d_in, w_in, eid_in)
+        assert G.nnz == skey.numel(), what
+        assert torch.equal(G.rowptr.long(), rowptr), what + ": rowptr"
+        assert torch.equal(G.row_ids().long() * n + G.col.long(), skey), what + ": (row, col) keys"
+        assert torch.equal(G.eid.long(), eid), what + ": input positions"
+        assert torch.equal(G.val, wv), what + ": values"
+        del skey, order, rowptr, wv, eid
+        # transposed operator (the backward's A^T): rows = sources, entries ordered by (destination, CSR position)
+        T = G.transpose()
+        r, c = G.row_ids().long(), G.col.long()
+        tkey, torder = torch.sort(c * n + r, stable=True)
+        trp = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        trp[1:] = torch.cumsum(torch.bincount(c, minlength=n), 0)
+        assert torch.equal(T.rowptr.long(), trp), what + ": transposed rowptr"
+        assert torch.equal(T.row_ids().long() * n + T.col.long(), tkey), what + ": transposed keys"
+        assert torch.equal(T.pos.long(), torder), what + ": transposed positions"
+        assert torch.equal(T.val, G.val[torder]), what + ": transposed values"
+
+    # TF flavour: SparseAdj(edge_index, w).add_self_loop() — N loops of weight `fill` appended, nothing removed
+    G = ga.CSRGraph.from_edge_index(ei, n, w, add_self_loops=True, fill=2.0)
+    check(G, torch.cat([src, ar]), torch.cat([dst, ar]), torch.cat([w, torch.full((n,), 2.0, device=dev)]),
+          torch.cat([torch.arange(E, device=dev), -1 - ar]), "add_self_loop")
+    del G
+    torch.cuda.empty_cache()
+    # PyG flavour: add_remaining_self_loops — input loops dropped, one loop per node re-added carrying the old weight
+    G = ga.CSRGraph.from_edge_index(ei, n, w, remove_self_loops=True, add_self_loops=True, keep_loop_weight=True)
+    keep = src != dst
+    lw = torch.ones(n, device=dev)
+    lw[src[~keep]] = w[~keep]
+    check(G, torch.cat([src[keep], ar]), torch.cat([dst[keep], ar]), torch.cat([w[keep], lw]),
+          torch.cat([torch.arange(E, device=dev)[keep], -1 - ar]), "add_remaining_self_loops")
+    # and the by-destination / by-source degrees the normalisation uses, against float64 index_add
+    deg64 = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, G.row_ids().long(), G.val.double())
+    assert float(((G.degree("row").double() - deg64).abs() / deg64).max()) <= 1e-6
+    deg64 = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, G.col.long(), G.val.double())
+    assert float(((G.degree("col").double() - deg64).abs() / deg64).max()) <= 1e-6
 
 
 def test_edge_index_validation(dev):
@@ -118,7 +181,11 @@ def test_gcn_norm_matches_golden_both_flavours(dev, golden):
         ti, tw = z[f"{name}/tf_norm_index"], z[f"{name}/tf_norm_weight"]
         A = torch.zeros(n, n, dtype=torch.float64)
         A.index_put_((torch.from_numpy(ti[0]), torch.from_numpy(ti[1])), torch.from_numpy(tw).double(), accumulate=True)
-        close(_dense(G), A, 1e-6)
+        # the golden weights are the oracle's float32 evaluation; the float64 one is recomputed from the golden inputs
+        eic, wc = ei.cpu(), w.cpu()
+        s64 = both(lambda c: R.gcn_norm_adj(R.SparseAdj(torch.stack([eic[1], eic[0]]), c(wc), [n, n])))[0]
+        A64 = torch.zeros(n, n, dtype=torch.float64).index_put_((s64.row, s64.col), s64.edge_weight, accumulate=True)
+        close(_dense(G), (A64, A), what=f"{name}: TF gcn_norm_adj")
         # PyG: remaining loops, degree by source
         G = ga.CSRGraph.from_edge_index(ei, n, w, remove_self_loops=True, add_self_loops=True,
                                         keep_loop_weight=True).gcn_norm("col")
@@ -127,7 +194,9 @@ def test_gcn_norm_matches_golden_both_flavours(dev, golden):
             continue  # two loops on one node: which weight survives is unordered in the reference too
         A = torch.zeros(n, n, dtype=torch.float64)
         A.index_put_((torch.from_numpy(pi[1]), torch.from_numpy(pi[0])), torch.from_numpy(pw).double(), accumulate=True)
-        close(_dense(G), A, 1e-6)
+        e64, w64 = both(lambda c: R.pyg_gcn_norm(eic, n, c(wc)))[0]
+        A64 = torch.zeros(n, n, dtype=torch.float64).index_put_((e64[1], e64[0]), w64, accumulate=True)
+        close(_dense(G), (A64, A), what=f"{name}: PyG norm")
 
 
 def test_transpose_and_degree(dev):
@@ -141,8 +210,9 @@ def test_transpose_and_degree(dev):
     assert torch.equal(_dense(T), _dense(G).t())
     assert (T.val.cpu() == G.val.cpu()[T.pos.cpu().long()]).all()
     A = _dense(G)
-    close(G.degree("row"), A.sum(1), 1e-5)
-    close(G.degree("col"), A.sum(0), 1e-5)
+    # _dense(G) is float64: A.sum is the float64 reference; a degree is one number per row -> per-entry 1e-5
+    close(G.degree("row")[:, None], A.sum(1)[:, None], what="degree by destination")
+    close(G.degree("col")[:, None], A.sum(0)[:, None], what="degree by source")
     assert (G.row_ids().cpu().numpy() == np.repeat(np.arange(N), np.diff(G.rowptr.cpu().numpy()))).all()
 
 
@@ -157,11 +227,16 @@ def test_aggregation_matches_golden(dev, golden):
         w = torch.from_numpy(z[f"{name}/w"]).to(dev)
         Gu = ga.CSRGraph.from_edge_index(ei, n)
         Gw = ga.CSRGraph.from_edge_index(ei, n, w)
+        eic, wc = ei.cpu(), w.cpu()
         for d in (1, 3, 64):
             x = torch.from_numpy(z[f"{name}/x{d}"]).to(dev)
+            xc = x.cpu()
             for red in ("sum", "mean", "max"):
-                close(ops.spmm(Gu, x, red), z[f"{name}/agg_{red}_d{d}"])
-                close(ops.spmm(Gw, x, red), z[f"{name}/aggw_{red}_d{d}"])
+                # float64: the oracle on the golden inputs; float32: the committed golden output itself
+                r64 = both(lambda c: R.coo_aggregate(eic[1], eic[0], None, c(xc), n, red))[0]
+                close(ops.spmm(Gu, x, red), (r64, torch.from_numpy(z[f"{name}/agg_{red}_d{d}"])), what=f"{name} {red} d{d}")
+                r64 = both(lambda c: R.coo_aggregate(eic[1], eic[0], c(wc), c(xc), n, red))[0]
+                close(ops.spmm(Gw, x, red), (r64, torch.from_numpy(z[f"{name}/aggw_{red}_d{d}"])), what=f"{name} w {red} d{d}")
 
 
 @pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 63, 64, 96, 100, 128, 130, 256, 260, 512, 1024])
@@ -175,10 +250,11 @@ def test_feature_widths(dev, d):
     x = torch.randn(N, d, generator=g)
     G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev))
     for red in ("sum", "mean", "max"):
-        close(ops.spmm(G, x.to(dev), red), R.coo_aggregate(ei[1], ei[0], w, x, N, red))
+        close(ops.spmm(G, x.to(dev), red), both(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(x), N, red)), what=red)
     # a strided view (leading dimension > d) takes the same path
     xp = torch.randn(N, d + 4, generator=g)
-    close(ops.spmm(G, xp.to(dev)[:, :d], "sum"), R.coo_aggregate(ei[1], ei[0], w, xp[:, :d], N, "sum"))
+    close(ops.spmm(G, xp.to(dev)[:, :d], "sum"), both(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(xp[:, :d]), N, "sum")),
+          what="strided view")
 
 
 def test_ragged_edge_cases(dev):
@@ -206,7 +282,9 @@ def test_ragged_edge_cases(dev):
         for ww in (None, w):
             G = ga.CSRGraph.from_edge_index(ei.to(dev), N, None if ww is None else ww.to(dev))
             for red in ("sum", "mean", "max"):
-                close(ops.spmm(G, x.to(dev), red), R.coo_aggregate(ei[1], ei[0], ww, x, N, red))
+                close(ops.spmm(G, x.to(dev), red),
+                      both(lambda c: R.coo_aggregate(ei[1], ei[0], None if ww is None else c(ww), c(x), N, red)),
+                      what=f"ragged N={N} {red}")
 
 
 def test_plan_covers_every_row_once(dev):
@@ -244,7 +322,7 @@ def test_argmax_is_bit_exact_with_ties(dev):
     cols = G.col.cpu().long()
     ref_arg = R.coo_aggregate_argmax(rows, cols, None, x, N)          # same CSR-sorted entry order
     assert torch.equal(arg.cpu().long(), ref_arg)
-    close(y, R.coo_aggregate(rows, cols, None, x, N, "max"), 0.0)
+    assert torch.equal(y.cpu(), R.coo_aggregate(rows, cols, None, x, N, "max"))       # a max of inputs: exact
 
 
 def test_epilogue_fusion(dev):
@@ -256,8 +334,8 @@ def test_epilogue_fusion(dev):
     x = torch.randn(N, d, generator=g)
     b = torch.randn(d, generator=g)
     G = ga.CSRGraph.from_edge_index(ei.to(dev), N)
-    ref = torch.relu(R.coo_aggregate(ei[1], ei[0], None, x, N, "sum") + 1.25 * x + b)
-    close(ops.spmm(G, x.to(dev), "sum", self_scale=1.25, bias=b.to(dev), relu=True), ref)
+    ref = both(lambda c: torch.relu(R.coo_aggregate(ei[1], ei[0], None, c(x), N, "sum") + 1.25 * c(x) + c(b)))
+    close(ops.spmm(G, x.to(dev), "sum", self_scale=1.25, bias=b.to(dev), relu=True), ref, what="fused epilogue")
 
 
 @pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
@@ -277,19 +355,24 @@ def test_backward_matches_oracle_autograd(dev, reduce):
     bg = b.to(dev).requires_grad_(True)
     y = ops.spmm(G, xg, reduce, self_scale=0.5, bias=bg, relu=True)
     y.backward(dy.to(dev))
-    xr = x.clone().requires_grad_(True)
-    br = b.clone().requires_grad_(True)
-    if reduce == "max":  # route the gradient to the same (CSR-order-first) winner the kernel picks
-        rows, cols = G.row_ids().cpu().long(), G.col.cpu().long()
-        wv = G.val.cpu()
-        agg = R.coo_aggregate(rows, cols, wv, xr, N, "max")
-    else:
-        agg = R.coo_aggregate(ei[1], ei[0], w, xr, N, reduce)
-    yr = torch.relu(agg + 0.5 * xr + br)
-    yr.backward(dy)
-    close(y, yr)
-    close(xg.grad, xr.grad)
-    close(bg.grad, br.grad, 1e-4)
+    mask = (y.detach() > 0).cpu()       # differentiate the oracle through the engine's ReLU pattern (inputs at ~0 are arbitrary)
+
+    def ref(c):
+        xr, br = c(x).clone().requires_grad_(True), c(b).clone().requires_grad_(True)
+        if reduce == "max":  # route the gradient to the same (CSR-order-first) winner the kernel picks
+            rows, cols = G.row_ids().cpu().long(), G.col.cpu().long()
+            agg = R.coo_aggregate(rows, cols, c(G.val.cpu()), xr, N, "max")
+        else:
+            agg = R.coo_aggregate(ei[1], ei[0], c(w), xr, N, reduce)
+        pre = agg + 0.5 * xr + br
+        assert bool(((pre.detach() > 0) == mask)[pre.detach().abs() > 1e-5 * float(pre.detach().abs().max())].all())
+        yr = pre * mask.to(pre.dtype)
+        yr.backward(c(dy))
+        return yr.detach(), xr.grad, br.grad
+    r64, r32 = both(ref)
+    close(y, (r64[0], r32[0]), what=f"{reduce} forward")
+    close(xg.grad, (r64[1], r32[1]), what=f"{reduce} dx")
+    close_all(bg.grad, (r64[2], r32[2]), what=f"{reduce} dbias")
 
 
 def test_two_branch_aggregation(dev):
@@ -307,15 +390,19 @@ def test_two_branch_aggregation(dev):
     P, Q = ops.idgnn_aggregate(G, ids.to(dev), xg)
     dP, dQ = torch.randn(N, d, generator=g), torch.randn(N, d, generator=g)
     (P * dP.to(dev) + Q * dQ.to(dev)).sum().backward()
-    xr = x.clone().requires_grad_(True)
     sel = torch.zeros(N, 1)
     sel[ids] = 1
-    Pr = R.coo_aggregate(ei[1], ei[0], w, xr, N, "sum")
-    Qr = R.coo_aggregate(ei[1], ei[0], w, xr * sel, N, "sum")
-    (Pr * dP + Qr * dQ).sum().backward()
-    close(P, Pr)
-    close(Q, Qr)
-    close(xg.grad, xr.grad)
+
+    def ref(c):
+        xr = c(x).clone().requires_grad_(True)
+        Pr = R.coo_aggregate(ei[1], ei[0], c(w), xr, N, "sum")
+        Qr = R.coo_aggregate(ei[1], ei[0], c(w), xr * c(sel), N, "sum")
+        (Pr * c(dP) + Qr * c(dQ)).sum().backward()
+        return Pr.detach(), Qr.detach(), xr.grad
+    r64, r32 = both(ref)
+    close(P, (r64[0], r32[0]), what="P = A x")
+    close(Q, (r64[1], r32[1]), what="Q = A S x")
+    close(xg.grad, (r64[2], r32[2]), what="two-branch dx")
     # rows with no identity neighbour are exactly zero
     has = torch.zeros(N).index_add_(0, ei[1], sel[ei[0]].view(-1)) > 0
     assert float(Q.detach().cpu()[~has].abs().max()) == 0.0
@@ -329,7 +416,7 @@ def test_identity_row_update(dev):
     ids = torch.tensor([3, 9, 0, 49, 17, 21, 8])
     hg, ug = h.to(dev).requires_grad_(True), u.to(dev).requires_grad_(True)
     out = ops.index_add_rows(hg, ids.to(dev), ug)
-    close(out, h.index_add(0, ids, u), 0.0)
+    assert torch.equal(out.detach().cpu(), h.index_add(0, ids, u))                 # one add per element: exact
     out.sum().backward()
     assert torch.equal(hg.grad.cpu(), torch.ones(50, 20)) and torch.equal(ug.grad.cpu(), torch.ones(7, 20))
     xs = ops.gather_rows(hg, ids.to(dev))
@@ -352,30 +439,34 @@ def test_attention_pieces(dev):
     y = ops.spmm_edge_values(G, p, Vg, H)
     dy = torch.randn(N, d, generator=g)
     y.backward(dy.to(dev))
-    Qr, Kr, Vr = (t.clone().requires_grad_(True) for t in (Q, K, V))
     dh = d // H
-    sr = (Qr[rows].view(-1, H, dh) * Kr[cols].view(-1, H, dh)).sum(-1) * 0.5
-    pr = R.softmax(sr, rows, N)
-    yr = torch.zeros(N, H, dh).index_add_(0, rows, pr.unsqueeze(-1) * Vr[cols].view(-1, H, dh)).view(N, d)
-    yr.backward(dy)
-    close(s, sr)
-    close(p, pr)
-    close(y, yr)
-    close(Qg.grad, Qr.grad, 1e-4)
-    close(Kg.grad, Kr.grad, 1e-4)
-    close(Vg.grad, Vr.grad, 1e-4)
+
+    def ref(c):
+        Qr, Kr, Vr = (c(t).clone().requires_grad_(True) for t in (Q, K, V))
+        sr = (Qr[rows].view(-1, H, dh) * Kr[cols].view(-1, H, dh)).sum(-1) * 0.5
+        pr = R.softmax(sr, rows, N)
+        yr = torch.zeros(N, H, dh, dtype=sr.dtype).index_add_(0, rows, pr.unsqueeze(-1) * Vr[cols].view(-1, H, dh)).view(N, d)
+        yr.backward(c(dy))
+        return sr.detach(), pr.detach(), yr.detach(), Qr.grad, Kr.grad, Vr.grad
+    r64, r32 = both(ref)
+    for got, i, what in ((s, 0, "scores"), (p, 1, "softmax"), (y, 2, "attention output"), (Qg.grad, 3, "dQ"),
+                         (Kg.grad, 4, "dK"), (Vg.grad, 5, "dV")):
+        close(got, (r64[i], r32[i]), what=what)
     # additive scores
     ai, aj = torch.randn(N, generator=g), torch.randn(N, generator=g)
     aig, ajg = ai.to(dev).requires_grad_(True), aj.to(dev).requires_grad_(True)
     sa = ops.sddmm_add(G, aig, ajg, 0.2)
     ds = torch.randn(G.nnz, 1, generator=g)
     sa.backward(ds.to(dev))
-    air, ajr = ai.clone().requires_grad_(True), aj.clone().requires_grad_(True)
-    sar = torch.nn.functional.leaky_relu(air[rows] + ajr[cols], 0.2).view(-1, 1)
-    sar.backward(ds)
-    close(sa, sar)
-    close(aig.grad, air.grad, 1e-4)
-    close(ajg.grad, ajr.grad, 1e-4)
+    def ref_add(c):
+        air, ajr = c(ai).clone().requires_grad_(True), c(aj).clone().requires_grad_(True)
+        sar = torch.nn.functional.leaky_relu(air[rows] + ajr[cols], 0.2).view(-1, 1)
+        sar.backward(c(ds))
+        return sar.detach(), air.grad, ajr.grad
+    r64, r32 = both(ref_add)
+    close(sa, (r64[0], r32[0]), what="additive scores")
+    close(aig.grad[:, None], (r64[1][:, None], r32[1][:, None]), what="d a_dst")      # one number per node: per entry
+    close(ajg.grad[:, None], (r64[2][:, None], r32[2][:, None]), what="d a_src")
 
 
 # --------------------------------------------------------------------------- full-size properties
@@ -394,10 +485,10 @@ def test_full_size_properties_c2_and_c4(dev):
         y = ops.spmm(G, ones, "sum")
         rows_all = G.row_ids().long()
         deg64 = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, rows_all, G.val.double())
-        assert float(((y[:, 0].double() - deg64).abs() / deg64.clamp(min=1.0)).max()) <= 1e-5
+        assert float(((y[:, 0].double() - deg64).abs() / deg64).max()) <= 1e-5      # per row, against its own float64 sum
         del rows_all
         deg = G.degree("row")                                            # the library's own K6 kernel
-        assert float(((deg.double() - deg64).abs() / deg64.clamp(min=1.0)).max()) <= 5e-5
+        assert float(((deg.double() - deg64).abs() / deg64).max()) <= 1e-5
         assert float((y - y[:, :1]).abs().max()) == 0.0                 # every column identical
         del ones, y
         gen = torch.Generator(device=dev).manual_seed(7)
@@ -415,11 +506,14 @@ def test_full_size_properties_c2_and_c4(dev):
         rows = torch.randint(0, n, (512,), device=dev, generator=gen)
         rows = torch.cat([rows, torch.arange(0, 8, device=dev)])        # the hubs too
         rp = G.rowptr.long()
+        r64, r32 = [], []
         for r in rows.tolist():
             s, e = int(rp[r]), int(rp[r + 1])
-            ref = (G.val[s:e, None].cpu() * x[G.col[s:e].long()].cpu())
-            ref = torch.zeros(1, d).index_add_(0, torch.zeros(e - s, dtype=torch.int64), ref)
-            close(y[r:r + 1], ref)
+            val, xg = G.val[s:e, None].cpu(), x[G.col[s:e].long()].cpu()
+            seg = torch.zeros(e - s, dtype=torch.int64)
+            r32.append(torch.zeros(1, d).index_add_(0, seg, val * xg))
+            r64.append(torch.zeros(1, d, dtype=torch.float64).index_add_(0, seg, val.double() * xg.double()))
+        close(y[rows], (torch.cat(r64), torch.cat(r32)), what=f"n={n}: sampled rows")
         del x, y, G
         torch.cuda.empty_cache()
 
@@ -444,13 +538,16 @@ def test_fused_eval_epilogue(dev, d):
     bn.eval()
     conv_bias = torch.randn(d, generator=g)
     G = ga.CSRGraph.from_edge_index(ei.to(dev), N)
-    agg = R.coo_aggregate(ei[1], ei[0], None, x, N, "sum") + 0.5 * x + conv_bias
-    ref = torch.nn.functional.normalize(torch.relu(bn(agg)), p=2, dim=-1).detach()
+    def ref(c):
+        agg = R.coo_aggregate(ei[1], ei[0], None, c(x), N, "sum") + 0.5 * c(x) + c(conv_bias)
+        h = torch.nn.functional.batch_norm(agg, c(bn.running_mean), c(bn.running_var), c(bn.weight.detach()),
+                                           c(bn.bias.detach()), False, 0.1, bn.eps)
+        return torch.nn.functional.normalize(torch.relu(h), p=2, dim=-1)
     scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
     shift = bn.bias + (conv_bias - bn.running_mean) * scale
     y = ops.spmm_fused_eval(G, x.to(dev), "sum", self_scale=0.5, col_scale=scale.detach().to(dev),
                             col_shift=shift.detach().to(dev), relu=True, l2norm=True)
-    close(y, ref)
+    close(y, both(ref), what="folded eval epilogue")
 
 
 def test_randomised_graphs_under_a_tiny_plan(dev):
@@ -478,13 +575,14 @@ def test_randomised_graphs_under_a_tiny_plan(dev):
                 G = ga.CSRGraph.from_edge_index(ei.to(dev), N, None if ww is None else ww.to(dev))
                 for red in ("sum", "mean", "max"):
                     close(ops.spmm(G, x.to(dev), red),
-                          R.coo_aggregate(ei[1], ei[0], None if ww is None else ww.double(), x.double(), N, red))
+                          both(lambda c: R.coo_aggregate(ei[1], ei[0], None if ww is None else c(ww), c(x), N, red)),
+                          what=f"tiny plan, trial {trial} {red}")
             ids = torch.randperm(N, generator=g)[:max(1, N // 10)]
             G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev))
             P, Q = ops.idgnn_aggregate(G, ids.to(dev), x.to(dev))
             sel = torch.zeros(N, 1); sel[ids] = 1
-            close(P, R.coo_aggregate(ei[1], ei[0], w.double(), x.double(), N, "sum"))
-            close(Q, R.coo_aggregate(ei[1], ei[0], w.double(), (x * sel).double(), N, "sum"))
+            close(P, both(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(x), N, "sum")), what=f"tiny plan P, trial {trial}")
+            close(Q, both(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(x * sel), N, "sum")), what=f"tiny plan Q, trial {trial}")
     finally:
         ga.CSRGraph.PLAN_CONFIG = None
 
@@ -501,24 +599,28 @@ def test_dense_fused_mfma_kernel(dev, M, F, d, dual):
     P, Q = torch.randn(M, F, generator=g), torch.randn(M, F, generator=g)
     W, Wi = torch.randn(F, d, generator=g) / F ** 0.5, torch.randn(F, d, generator=g) / F ** 0.5
     b = torch.randn(d, generator=g)
-    ref = P.double() @ W.double() + b.double()
-    if dual:
-        ref = ref + Q.double() @ Wi.double()
-    ref = torch.relu(ref)
     args = [t.to(dev).requires_grad_(True) for t in (P, W, Q, Wi, b)]
     out = ops.dense_fused(args[0], args[1], args[2] if dual else None, args[3] if dual else None, args[4], relu=True)
-    close(out, ref, 1e-5)
     dy = torch.randn(M, d, generator=g)
     out.backward(dy.to(dev))
-    refs = [t.clone().requires_grad_(True) for t in (P, W, Q, Wi, b)]
-    r = refs[0] @ refs[1] + refs[4]
-    if dual:
-        r = r + refs[2] @ refs[3]
-    torch.relu(r).backward(dy)
-    for a, rr, name in zip(args, refs, "P W Q Wid b".split()):
+    mask = (out.detach() > 0).cpu()                      # the oracle differentiates through the engine's ReLU pattern
+
+    def ref(c):
+        refs = [c(t).clone().requires_grad_(True) for t in (P, W, Q, Wi, b)]
+        r = refs[0] @ refs[1] + refs[4]
+        if dual:
+            r = r + refs[2] @ refs[3]
+        assert bool(((r.detach() > 0) == mask)[r.detach().abs() > 1e-5 * float(r.detach().abs().max())].all())
+        o = r * mask.to(r.dtype)
+        o.backward(c(dy))
+        return [o.detach()] + [t.grad for t in refs]
+    r64, r32 = both(ref)
+    close(out, (r64[0], r32[0]), what="transform forward")
+    for i, (a, name) in enumerate(zip(args, "P W Q Wid b".split())):
         if not dual and name in ("Q", "Wid"):
             continue
-        close(a.grad, rr.grad, 2e-4)
+        # input gradients are per row; weight / bias gradients are reductions over all M rows: one scale
+        (close if name in ("P", "Q") else close_all)(a.grad, (r64[1 + i], r32[1 + i]), what=f"transform d{name}")
     # the raw kernel really ran for these shapes (no library fallback)
     assert ops._raw_dense_fused(P.to(dev), W.to(dev), None, None, None, False) is not None
 
@@ -584,9 +686,10 @@ def test_by_source_normalisation_is_bitwise_reproducible(dev):
                                         keep_loop_weight=True).gcn_norm("col")
         builds.append(G.val.clone())
     assert torch.equal(builds[0], builds[1])
-    ei_r, norm_r = R.pyg_gcn_norm(ei, N, w)
-    ref = torch.zeros(N, N, dtype=torch.float64).index_put_((ei_r[1], ei_r[0]), norm_r.double(), accumulate=True)
-    close(_dense(G), ref, 1e-5)
+    def ref(c):
+        ei_r, norm_r = R.pyg_gcn_norm(ei, N, c(w))
+        return torch.zeros(N, N, dtype=norm_r.dtype).index_put_((ei_r[1], ei_r[0]), norm_r, accumulate=True)
+    close(_dense(G), both(ref), what="PyG normalisation by source degree")
 
 
 @pytest.mark.parametrize("heads,d", [(2, 64), (4, 256), (8, 128), (4, 24)])
@@ -610,15 +713,20 @@ def test_multi_head_aggregation_in_one_launch(dev, heads, d):
     dh = d // heads
     w = a.double().repeat_interleave(dh, dim=1)                    # [nnz, d]: head h's weight on its dh columns
     ref = torch.zeros(N, d, dtype=torch.float64).index_add_(0, rows, w * V.double()[cols])
-    close(y, ref)
     ad, Vd = a.to(dev).requires_grad_(True), V.to(dev).requires_grad_(True)
     up = torch.randn(N, d, generator=g)
     ops.spmm_edge_values(G, ad, Vd, heads).backward(up.to(dev))
-    ar, Vr = a.double().requires_grad_(True), V.double().requires_grad_(True)
-    torch.zeros(N, d, dtype=torch.float64).index_add_(
-        0, rows, ar.repeat_interleave(dh, dim=1) * Vr[cols]).backward(up.double())
-    close(ad.grad, ar.grad, 2e-5)
-    close(Vd.grad, Vr.grad, 2e-5)
+
+    def ref_fn(c):
+        ar, Vr = c(a).clone().requires_grad_(True), c(V).clone().requires_grad_(True)
+        o = torch.zeros(N, d, dtype=ar.dtype).index_add_(0, rows, ar.repeat_interleave(dh, dim=1) * Vr[cols])
+        o.backward(c(up))
+        return o.detach(), ar.grad, Vr.grad
+    r64, r32 = both(ref_fn)
+    assert float((r64[0] - ref).abs().max()) == 0.0
+    close(y, (r64[0], r32[0]), what="multi-head aggregation")
+    close(ad.grad, (r64[1], r32[1]), what="d alpha")
+    close(Vd.grad, (r64[2], r32[2]), what="dV")
 
 
 @pytest.mark.parametrize("heads", [1, 4])
@@ -638,12 +746,15 @@ def test_additive_attention_coefficients_in_one_pass(dev, heads):
     adg, asg = a_dst.to(dev).requires_grad_(True), a_src.to(dev).requires_grad_(True)
     alpha = ops.gat_alpha(G, adg, asg, 0.2)
     alpha.backward(dal.to(dev))
-    adr, asr = a_dst.double().requires_grad_(True), a_src.double().requires_grad_(True)
-    s = torch.nn.functional.leaky_relu(adr[rows] + asr[cols], 0.2)
-    ref = R.softmax(s, rows, N)
-    ref.backward(dal.double())
-    close(alpha, ref)
-    close(adg.grad, adr.grad, 2e-5)
-    close(asg.grad, asr.grad, 2e-5)
+    def ref_fn(c):
+        adr, asr = c(a_dst).clone().requires_grad_(True), c(a_src).clone().requires_grad_(True)
+        s = torch.nn.functional.leaky_relu(adr[rows] + asr[cols], 0.2)
+        r = R.softmax(s, rows, N)
+        r.backward(c(dal))
+        return r.detach(), adr.grad, asr.grad
+    r64, r32 = both(ref_fn)
+    close(alpha, (r64[0], r32[0]), what="additive attention coefficients")
+    close(adg.grad, (r64[1], r32[1]), what="d a_dst")
+    close(asg.grad, (r64[2], r32[2]), what="d a_src")
     sums = torch.zeros(N, heads, dtype=torch.float64).index_add_(0, rows, alpha.detach().cpu().double())
     assert float((sums - 1.0).abs().max()) <= 1e-5                  # every row has its self loop: coefficients sum to 1

@@ -128,3 +128,107 @@ def test_narrow_head_linear_backward(dev):
     assert_close_all(lin.weight.grad, ref.weight.grad, 1e-5, ref32=(up.t() @ x), what="dW")
     assert_close_all(lin.bias.grad, ref.bias.grad, 1e-5, ref32=up.sum(0), what="db")
     assert_close_all(xd.grad, xr.grad, 1e-5, what="dx")
+
+
+def test_softmax_cross_entropy_input_contract(dev):
+    """labels / index are validated — a length mismatch raises on the host, an out-of-range label (torch's
+    ignore_index -100 is not implemented) or index is never dereferenced and poisons the loss with NaN, and a row
+    listed twice in the index accumulates both gradient terms like F.cross_entropy(logits[index])"""
+    g = torch.Generator().manual_seed(5)
+    N, Cn = 200_000, 8
+    z = torch.randn(N, Cn, generator=g)
+    y = torch.randint(0, Cn, (N,), generator=g)
+    zd = z.to(dev)
+    with pytest.raises((ValueError, RuntimeError)):
+        torch.ops.mp.softmax_ce(zd, y.to(dev)[: N // 2], torch.arange(N // 2 + 1, device=dev))
+    with pytest.raises((ValueError, RuntimeError)):
+        torch.ops.mp.softmax_ce(zd[: N // 2], y.to(dev), None)
+    bad = y.clone(); bad[12345] = -100
+    assert torch.isnan(torch.ops.mp.softmax_ce(zd, bad.to(dev), None))
+    bad = y.clone(); bad[7] = Cn
+    rows = torch.ops.mp.softmax_ce_rows_raw(zd, bad.to(dev), None)
+    assert torch.isnan(rows[7]) and not torch.isnan(rows[8:]).any() and not torch.isnan(rows[:7]).any()
+    idx = torch.arange(N); idx[99] = N + 5
+    assert torch.isnan(torch.ops.mp.softmax_ce(zd, y.to(dev), idx.to(dev)))
+    dz = torch.ops.mp.softmax_ce_bwd_raw(zd, y.to(dev), idx.to(dev), torch.ones((), device=dev), 1.0 / N)
+    assert torch.isfinite(dz).all() and float(dz[99].abs().max()) == 0.0        # no gradient through the bad entry
+    # duplicates in the index: both terms arrive
+    idx = torch.randint(0, N // 4, (N,), generator=g)                             # every row ~4 times
+    zr = z.double().requires_grad_(True)
+    F.cross_entropy(zr[idx], y, reduction="mean").backward()
+    zq = zd.clone().requires_grad_(True)
+    torch.ops.mp.softmax_ce(zq, y.to(dev), idx.to(dev)).backward()
+    assert_close_all(zq.grad, zr.grad, 1e-5, what="dlogits with a non-unique index")
+    # fewer labels than rows without an index: the unlabelled rows get exact zeros
+    zq = zd.clone().requires_grad_(True)
+    torch.ops.mp.softmax_ce(zq, y.to(dev)[: N // 2], None).backward()
+    assert float(zq.grad[N // 2:].abs().max()) == 0.0
+
+
+def test_bf16x3_split_follows_in_place_weight_updates(dev):
+    """the bf16x3 split of W must not be cached across calls on `_version` — `w.data.uniform_()` (glorot /
+    reset_parameters, idconv.py:125-128) rewrites W without bumping it"""
+    import graphgym_amd as ga
+    from graphgym_amd import graphgen, layers, ops
+    n, d = 4000, 256
+    ei = graphgen.ba_edge_index(n, 4, seed=2).to(dev)
+    g = ga.CSRGraph.from_edge_index(ei, n, add_self_loops=True).gcn_norm("row")
+    gen = torch.Generator().manual_seed(1)
+    x = (torch.rand(n, d, generator=gen) * 2 - 1).to(dev)
+    W = torch.nn.Parameter(torch.empty(d, d, device=dev))
+    layers.glorot(W)
+    out1, _ = ops._raw_agg_dense(g, x, W.detach(), bf16x3=True)
+    v = W._version
+    layers.glorot(W)                                   # .data.uniform_: same storage, same _version
+    assert W._version == v
+    out2, _ = ops._raw_agg_dense(g, x, W.detach(), bf16x3=True)
+    ref2, _ = ops._raw_agg_dense(g, x, W.detach(), bf16x3=False)
+    assert not torch.equal(out1, out2)
+    from _tol import assert_close_rows
+    assert_close_rows(out2, ref2.double(), 2e-6, what="bf16x3 after an in-place re-initialisation")
+
+
+def test_ginidconv_forward_reads_no_device_scalar_and_captures(dev):
+    """`float(self.eps)` on the device buffer was a host sync per forward and broke HIP-graph capture;
+    eps is now carried as a host float that follows the constructor and load_state_dict"""
+    from graphgym_amd import graphgen, layers
+    from graphgym_amd.harness import Batch
+    n, d = 3000, 64
+    ei = graphgen.ba_edge_index(n, 3, seed=4).to(dev)
+    ids = torch.arange(0, n, 10, device=dev)
+    layer = layers.GINIDConv(d, d).to(dev)
+    sd = layer.state_dict()
+    assert "model.eps" in sd                                             # the reference's buffer (idconv.py:361)
+    sd["model.eps"] = torch.tensor([0.25])
+    layer.load_state_dict(sd)
+    assert layer.model._eps_value() == 0.25 and float(layer.model.eps) == 0.25
+    x = torch.randn(n, d, device=dev)
+    b = Batch(node_feature=x.clone(), edge_index=ei, node_id_index=ids)
+    with torch.no_grad():
+        eager = layer(b).node_feature.clone()                            # warm the CSR cache
+        b.node_feature = x.clone()
+        static_in = b.node_feature
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            b.node_feature = static_in
+            layer(b)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        b.node_feature = static_in
+        with torch.cuda.graph(graph):
+            out = layer(b).node_feature
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    # oracle: GINIDConvLayer.forward restated (idconv.py:367-376), float64, eps = 0.25
+    from oracle import ref_layers as RL
+    from _tol import assert_close_rows
+    m = layer.model
+    p64 = lambda t: t.detach().cpu().double()
+
+    def mlp(seq):
+        w0, b0, w1, b1 = p64(seq[0].weight), p64(seq[0].bias), p64(seq[2].weight), p64(seq[2].bias)
+        return lambda t: torch.relu(t @ w0.t() + b0) @ w1.t() + b1
+    ref = RL.ginid_conv(x.cpu().double(), ei.cpu(), ids.cpu(), mlp(m.nn), mlp(m.nn_id), eps=0.25)
+    assert_close_rows(out, ref, 1e-5, what="ginidconv with eps = 0.25")
