@@ -19,8 +19,11 @@ Prints ONE JSON line on rank 0.  `roofline` prices the aggregation launch agains
 times the CPU oracle (the op-for-op restatement of the reference's CPU path) on a bounded sample of the
 same workload on this box's host cores.
 
-X and Y are allocated through the engine (graphgym_amd/placement.py): Y lands where it conflicts least
-with X — the same call the product's operators make for their outputs; there is no candidate loop here.
+X is a plain torch tensor (what a GraphGym first layer is handed).  Y is allocated ONCE by the very call the product's
+operators make for their outputs (graphgym_amd.placement.empty_or_torch(reads=(X,)): a torch allocation, a timed-copy
+check against X, re-allocation on conflict — at most MP_PLACE_TRIES candidates); `value` and `roofline` are measured on
+that Y.  Side fields, never part of `value`: the same launch with Y as torch hands it out unchecked
+(`output_placement.unchecked_ms`) and with the best of 8 candidates (`output_placement.best_of_8_ms`).
 """
 import argparse
 import json
@@ -141,18 +144,28 @@ def run_aggregate(args, rank, world, dev):
     g.plan()
     torch.cuda.empty_cache()
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
-    # resident feature matrix and the output, both through the engine's placement (the call ops.spmm makes)
-    x = placement.empty((n, d), torch.float32, dev)     # None below the size where placement matters
-    x_engine = x is not None
-    if x is None:
-        x = torch.empty((n, d), dtype=torch.float32, device=dev)
+    # the resident feature matrix: a plain torch tensor; the output: the allocation ops._raw_spmm makes for itself
+    x = torch.empty((n, d), dtype=torch.float32, device=dev)
     x.uniform_(-1.0, 1.0, generator=gen)
-    y = placement.empty_or_torch((n, d), dev, reads=(x,), verify="all")   # resident output: every free position timed once (~0.2 s of set-up)
-    ar = placement.arena(dev, create=False)
-    place = {"engine_placed": bool(ar is not None and ar.owns(y)), "x_in_arena": bool(x_engine),
-             "predicted_conflict": getattr(y, "_mp_predicted_conflict", None),
-             "verified_candidates_ms": getattr(y, "_mp_verified_candidates_ms", None),
-             "arena": None if ar is None else ar.stats()}
+
+    def time_into(yy, reps=5):
+        ops._raw_spmm(g, x, _lib.SUM, out=yy)
+        return _ms(lambda: ops._raw_spmm(g, x, _lib.SUM, out=yy), reps=reps)
+
+    place = {"mode": "product: placement.empty_or_torch(reads=(X,)) — torch allocation, copy-probe check, re-allocation on "
+                     "conflict (the call every operator makes for a >= 1 GiB output)", "x": "torch.empty (foreign tensor)"}
+    if world == 1 and placement.enabled():
+        y_plain = torch.empty((n, d), dtype=torch.float32, device=dev)      # what torch hands out, unchecked
+        place["unchecked_ms"] = time_into(y_plain)
+        del y_plain
+    y = placement.empty_or_torch((n, d), dev, reads=(x,))
+    place.update(getattr(y, "_mp_place", {}) or {})
+    place["stats"] = placement.stats(dev)
+    if world == 1 and placement.enabled():
+        y8 = placement.empty_or_torch((n, d), dev, reads=(x,), tries=8, accept=-1.0)    # all 8 timed, the fastest kept
+        place["best_of_8_ms"] = time_into(y8) if y8.data_ptr() != y.data_ptr() else None
+        place["best_of_8_candidates_ms"] = (getattr(y8, "_mp_place", {}) or {}).get("candidates_ms")
+        del y8
 
     def step():
         ops._raw_spmm(g, x, _lib.SUM, out=y)
@@ -265,8 +278,7 @@ def run_aggregate(args, rank, world, dev):
                                 " seed 12345+rank, symmetrised, deduplicated, self loops added" +
                                 (", nodes randomly relabelled" if args.permute else ""),
                        "index_dtype": "int32",
-                       "output_placement": dict(place, note="X and Y allocated once through graphgym_amd.placement "
-                                                "(the allocation ops.spmm makes for its output); no candidate loop"),
+                       "output_placement": place,
                        "parallelism": f"{world} independent graph(s), one per GPU, no data-path collective"},
             "hbm_gbps_algorithmic": achieved,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -308,6 +320,13 @@ def main():
 
     from graphgym_amd import dist as D
 
+    if args.mode == "step" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # a one-rank step still EXECUTES its exchange (a one-rank RCCL group runs the same communicator set-up, stream
+        # hand-off and async work objects as an 8-rank one): nothing RCCL-side is first run when the node appears
+        os.environ.setdefault("MP_DIST_FORCE", "1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
     rank, local, world = D.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")

@@ -32,13 +32,8 @@ PROTOTYPES = {
     "mp_read_probe_f32": (C.c_int, [_p, _i64, _p, _p]),
     "mp_status_str": (C.c_char_p, [C.c_int]),
     "mp_last_hip_error": (C.c_char_p, []),
-    "mp_arena_create": (C.c_int, [_sz]),
-    "mp_arena_destroy": (C.c_int, []),
-    "mp_arena_info": (C.c_int, [C.POINTER(C.c_void_p), _psz, _psz, _psz]),
-    "mp_arena_alloc_placed": (C.c_int, [_sz, _p, _i32, _sz, C.POINTER(C.c_void_p)]),
-    "mp_arena_release": (C.c_int, [_p]),
-    "mp_arena_dlpack": (C.c_int, [_p, _i32, _p, _i32, _i32, C.POINTER(C.c_void_p)]),
     "mp_probe_copy_ms": (C.c_int, [_p, _p, _sz, _i32, C.POINTER(C.c_float), _p]),
+    "mp_probe_gather_ms": (C.c_int, [_p, _sz, _p, _sz, _i32, _i32, C.POINTER(C.c_float), _p]),
     "mp_csr_from_coo_ws_bytes": (C.c_int, [_i64, _i64, _psz]),
     "mp_csr_from_coo": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _f32, _p, _p, _p, _p, _p, _sz, _p]),
     "mp_check_edge_index": (C.c_int, [_p, _p, _i64, _i64, _p, _p]),

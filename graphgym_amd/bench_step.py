@@ -109,7 +109,7 @@ def run(args, rank, world, dev):
     reps = 20
     for _ in range(reps):
         for flat, _ in bucket.buckets:
-            bucket._reduce(flat, async_op=False) if D.dist.is_initialized() and world > 1 else None
+            bucket._reduce(flat, async_op=False) if bucket._active() else None
     torch.cuda.synchronize()
     t_ar = D.all_reduce_max((time.perf_counter() - t0) / reps, dev)
 
@@ -127,6 +127,8 @@ def run(args, rank, world, dev):
             "ms_per_step_no_exchange": dt_local / args.steps * 1e3,
             "allreduce_exposed_ms": exposed, "allreduce_ms": t_ar * 1e3,
             "allreduce_bytes": 4 * n_par, "allreduce_buckets": len(bucket.buckets),
+            "collective_backend": D.dist.get_backend() if D.dist.is_initialized() else None,
+            "collectives_executed": bool(bucket._active()),
             "step_efficiency_vs_no_exchange": dt_local / dt,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"idgcn_tf_step_ego_r{radius}_d{d}_BA_n{n0}_m{args.m}_c{args.centres}x{world}",

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libmpengine.so")
-SOURCES = ["spmm.hip", "fused.hip", "csr_build.hip", "attn.hip", "ego.hip", "gemm.hip", "dense_x3.hip", "bn.hip", "util.hip", "arena.hip", "loss.hip"]
+SOURCES = ["spmm.hip", "fused.hip", "csr_build.hip", "attn.hip", "ego.hip", "gemm.hip", "dense_x3.hip", "bn.hip", "util.hip", "probe.hip", "loss.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "vecio.h"), os.path.join(CSRC, "bf16x3.h"), os.path.join(ROOT, "include", "mp_engine.h")]
 ARCH = "gfx950"
 

@@ -28,8 +28,16 @@ def lpt_partition(costs, world_size):
     return parts
 
 
+def force_collectives():
+    """MP_DIST_FORCE=1: run every collective even in a one-rank group.  A one-rank RCCL group executes the same code
+    (communicator set-up, stream hand-off, the async work objects, reduce_scatter_tensor / all_gather_into_tensor) as an
+    8-rank one, which is how the RCCL branches are exercised on the one GPU a test box has
+    (tests/test_rccl_gpu.py, bench.py --mode step)."""
+    return os.environ.get("MP_DIST_FORCE") == "1"
+
+
 def init_from_env(device_type=None):
-    """(rank, local_rank, world_size); initialises the process group when WORLD_SIZE > 1."""
+    """(rank, local_rank, world_size); initialises the process group when WORLD_SIZE > 1 (or MP_DIST_FORCE=1)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -39,7 +47,7 @@ def init_from_env(device_type=None):
         if os.environ.get("MP_SHARE_DEVICE") == "1":      # rehearsal of N ranks on a 1-GPU box (gloo only)
             local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("MP_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
@@ -90,8 +98,8 @@ class GradBucket:
     Averaging per-rank MEAN losses over ranks is a mean of means — not the full-batch gradient when shards hold
     different numbers of labelled nodes (LPT balances stored entries, not labels).  Normalise the loss by the GLOBAL
     count (``global_count``) and sum, as bench.py --mode step and tests/test_ddp_gpu.py do.
-    The RCCL ("nccl") branch has run on CPU/gloo and on one GPU shared by two gloo ranks only: no multi-GPU node was
-    available to this build."""
+    The RCCL ("nccl") branches run under -m gpu in a one-rank group (tests/test_rccl_gpu.py: MP_DIST_FORCE=1) and the
+    N > 1 logic under gloo with two ranks; no multi-GPU node was available to this build."""
 
     def __init__(self, params, n_buckets=1):
         self.params = [p for p in params if p.requires_grad]
@@ -125,7 +133,7 @@ class GradBucket:
 
     @staticmethod
     def _active():
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives())
 
     def _reduce(self, flat, async_op):
         if dist.get_backend() == "gloo" and flat.is_cuda:   # rehearsal mode (ranks sharing a GPU): stage through the host
@@ -152,10 +160,27 @@ class GradBucket:
         self._left = [len(views) for _, views in self.buckets]
         self._pending = []
 
+    def _check_views(self, bi=None):
+        """p.grad must still BE the bucket view: optimizer.zero_grad() with set_to_none=True (torch's default) drops it,
+        autograd then allocates a fresh p.grad, and the all-reduce would exchange a bucket nobody wrote — replicas
+        would diverge silently.  Use bucket.zero_grad() (or optimizer.zero_grad(set_to_none=False))."""
+        for i, (_, views) in enumerate(self.buckets):
+            if bi is not None and i != bi:
+                continue
+            for p, v in views:
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    raise RuntimeError("GradBucket: a parameter's .grad is no longer the bucket view (was "
+                                       "optimizer.zero_grad(set_to_none=True) called?); use GradBucket.zero_grad() "
+                                       "or re-attach")
+
     def _make_hook(self, bi):
         def hook(param):
+            if self._left[bi] <= 0:
+                raise RuntimeError("GradBucket: a gradient arrived for a bucket whose all-reduce was already launched "
+                                   "(a second backward before finish()); call finish() / zero_grad() between steps")
             self._left[bi] -= 1
             if self._left[bi] == 0 and self._active():
+                self._check_views(bi)
                 flat = self.buckets[bi][0]
                 if flat.is_cuda and dist.get_backend() != "gloo":
                     # the gradient kernels run on the current stream; the collective is enqueued behind them by
@@ -174,6 +199,8 @@ class GradBucket:
         """wait for the launched all-reduces (launch any bucket whose hooks did not all fire: parameters unused this
         step), then multiply by `scale` (1 / world for a mean of per-rank gradients; 1 for globally normalised losses)"""
         if self._active():
+            if self._attached:
+                self._check_views()
             for bi, left in enumerate(self._left):
                 if left > 0:
                     self._pending.append(self._reduce(self.buckets[bi][0], async_op=False))
@@ -252,21 +279,33 @@ class RowPartition:
 
 def _gather_rows(part, h_loc):
     """[rows_p, d] on every rank -> [N, d] everywhere (all-gather with padding to the widest range)"""
-    if part.world == 1:
+    if part.world == 1 and not (force_collectives() and dist.is_initialized()):
         return h_loc
     d = h_loc.size(1)
-    pad = torch.zeros((part.max_rows, d), dtype=h_loc.dtype, device=h_loc.device)
-    pad[:h_loc.size(0)] = h_loc
-    host = dist.get_backend() == "gloo" and pad.is_cuda
-    buf = [torch.empty_like(pad.cpu() if host else pad) for _ in range(part.world)]
-    dist.all_gather(buf, pad.cpu() if host else pad)
-    out = torch.cat([buf[p][:part.bounds[p + 1] - part.bounds[p]] for p in range(part.world)], dim=0)
-    return out.to(h_loc.device)
+    ragged = any(part.bounds[p + 1] - part.bounds[p] != part.max_rows for p in range(part.world))
+    if ragged:
+        pad = torch.zeros((part.max_rows, d), dtype=h_loc.dtype, device=h_loc.device)
+        pad[:h_loc.size(0)] = h_loc
+    else:
+        pad = h_loc.contiguous()
+    if dist.get_backend() == "gloo":
+        host = pad.is_cuda
+        buf = [torch.empty_like(pad.cpu() if host else pad) for _ in range(part.world)]
+        dist.all_gather(buf, pad.cpu() if host else pad)
+        out = torch.cat([buf[p][:part.bounds[p + 1] - part.bounds[p]] for p in range(part.world)], dim=0)
+        return out.to(h_loc.device)
+    # RCCL: one all_gather_into_tensor of equal (padded) chunks straight into the [world * max_rows, d] result
+    out = torch.empty((part.world * part.max_rows, d), dtype=h_loc.dtype, device=h_loc.device)
+    dist.all_gather_into_tensor(out, pad)
+    if not ragged:
+        return out
+    return torch.cat([out[p * part.max_rows: p * part.max_rows + part.bounds[p + 1] - part.bounds[p]]
+                      for p in range(part.world)], dim=0)
 
 
 def _scatter_sum_rows(part, full):
     """sum of [N, d] partials over ranks, each rank keeping its own rows (reduce-scatter)"""
-    if part.world == 1:
+    if part.world == 1 and not (force_collectives() and dist.is_initialized()):
         return full
     r0, r1 = part.rows
     if dist.get_backend() == "gloo":             # gloo has no reduce_scatter_tensor: all-reduce (staged through the host)

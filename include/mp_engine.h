@@ -78,36 +78,23 @@ const char* mp_status_str(int status);
 const char* mp_last_hip_error(void);
 
 /* ------------------------------------------------------------------ *
- * Placement-aware device arena (no counterpart in the reference: it     *
- * never places anything; this is the path's data layout in HBM).        *
- * On MI355X a launch that reads X and writes Y is up to ~15 % slower     *
- * depending on which physical memory backs the two (the high address    *
- * bits are hashed into the DRAM bank / channel selection; measured map: *
- * profiles/r02_placement_map.log).  The engine owns one slab per        *
- * device, measures the pairwise cost between its granules once          *
- * (mp_probe_copy_ms, driven by graphgym_amd/placement.py) and places    *
- * the outputs of mp_spmm_csr_f32 / mp_agg_dense_f32 / mp_idgnn_agg_f32   *
- * where they conflict least with what the launch reads.                 *
- * Exception to "nothing is allocated inside the library": the slab is   *
- * one hipMalloc in mp_arena_create, released by mp_arena_destroy.       *
- * All of these act on the calling thread's current HIP device.          *
+ * Placement probe (no counterpart in the reference: this belongs to the  *
+ * path's data layout in HBM).  On MI355X a launch that reads X and       *
+ * writes Y is up to ~13 % slower depending on which physical memory      *
+ * backs the two (high address bits are hashed into the DRAM bank /       *
+ * channel selection).  The library allocates nothing: outputs are the    *
+ * caller's buffers.  The host side (graphgym_amd/placement.py) times a   *
+ * copy between sample chunks of what a launch reads and a candidate      *
+ * output buffer with this entry point and re-allocates on conflict.      *
  * ------------------------------------------------------------------ */
-int mp_arena_create(size_t bytes);
-int mp_arena_destroy(void);      /* MP_ERR_INVALID_ARG while buffers are handed out */
-int mp_arena_info(void** base_host, size_t* bytes_host, size_t* in_use_host, size_t* largest_free_host);
-/* a free range of `bytes` (rounded up to 2 MiB) with the smallest mean penalty; penalty_host[g] prices granule g =
- * bytes [g * granule_bytes, (g + 1) * granule_bytes) of the slab, NULL = first fit; ties go to the lowest address;
- * MP_ERR_WORKSPACE when no free run is large enough */
-int mp_arena_alloc_placed(size_t bytes, const float* penalty_host, int32_t n_granules, size_t granule_bytes,
-                          void** ptr_host);
-int mp_arena_release(void* ptr);
-/* DLManagedTensor* (DLPack) over an arena buffer for torch.from_dlpack: contiguous, 1-4 dims, DLPack element type
- * (code, bits) — float32 = (2, 32); its deleter calls mp_arena_release.  Consume *managed_host exactly once. */
-int mp_arena_dlpack(void* ptr, int32_t ndim, const int64_t* shape_host, int32_t type_code, int32_t type_bits,
-                    void** managed_host);
 /* timed streaming copy (16 B per lane, non-temporal stores): one untimed launch, then `reps` launches between
  * two events; SYNCHRONISES `stream`; *ms_host = mean milliseconds per launch */
 int mp_probe_copy_ms(const void* src, void* dst, size_t bytes, int32_t reps, float* ms_host, mp_stream_t stream);
+/* timed gather probe — the access pattern of the aggregation itself: each of the dst_bytes / 1024 rows of dst is the
+ * sum of `fan` (1..64) pseudo-random 1 KiB rows taken from ALL of [src, src + src_bytes); one untimed launch, then
+ * `reps`; SYNCHRONISES `stream`.  Shows the placement effect at full size (+12-13 % good vs bad position of dst). */
+int mp_probe_gather_ms(const void* src, size_t src_bytes, void* dst, size_t dst_bytes, int32_t fan, int32_t reps,
+                       float* ms_host, mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * Graph construction: COO edge list -> destination-sorted CSR         *

@@ -47,6 +47,9 @@ def pytest_sessionfinish(session, exitstatus):
         worst = sorted((s for s in _tol.STATS if s["needed_ref32"]), key=lambda s: -s["frac"])[:40]
         with open(os.path.join(out, "tol_stats.json"), "w") as f:
             json.dump({"calls": calls, "calls_needing_ref32": sum(1 for s in _tol.STATS if s["needed_ref32"]),
-                       "rows": rows, "rows_needing_ref32": needed, "largest_fractions": worst}, f, indent=1)
+                       "rows": rows, "rows_needing_ref32": needed,
+                       "straggler_rows": sum(s.get("stragglers", 0) for s in _tol.STATS),
+                       "calls_with_stragglers": [s["what"] for s in _tol.STATS if s.get("stragglers")],
+                       "largest_fractions": worst}, f, indent=1)
     except Exception:
         pass

@@ -46,16 +46,22 @@ def test_batchnorm_training_parity(dev, N, d, relu):
         pre = torch.nn.functional.batch_norm(x.double(), None, None, w.double(), b.double(), True, 0.1, 1e-5)
         off = (pre > 0) != mask
         assert not bool(off.any()) or float(pre.abs()[off].max()) <= 1e-5 * float(pre.abs().max())
-    close(y, (r64[0], r32[0]), what="bn forward")
-    close(xg.grad, (r64[1], r32[1]), what="bn dx")
+    # column 0 is a stress column (mean 1000, unit variance): ANY float32 BatchNorm — torch's included — rounds that mean
+    # to float32 (half an ulp of 1000 = 3e-5 of the column's standard deviation), and the column sits in every row, so
+    # every row may need the float32 reference's own distance here; the median-ratio rule still holds the engine to it
+    close(y, (r64[0], r32[0]), what="bn forward", max_ref32_frac=1.0)
+    if N >= 8:
+        close(xg.grad, (r64[1], r32[1]), what="bn dx", max_ref32_frac=1.0)
+    else:   # a batch of two: x_hat = +-1 and dx is the rounding residue of terms that cancel exactly; one scale
+        close_all(xg.grad, (r64[1], r32[1]), what="bn dx (degenerate batch)")
     col = lambda t: t.detach().reshape(-1, 1)                      # one statistic per column: each its own scale
-    close(col(ours.weight.grad), (col(r64[2]), col(r32[2])), what="bn dgamma")
-    close_all(ours.bias.grad, (r64[3], r32[3]), what="bn dbeta")   # sums of dy: cancel to ~0, one scale
+    close_all(ours.weight.grad, (r64[2], r32[2]), what="bn dgamma")  # parameter gradients: reductions over all rows,
+    close_all(ours.bias.grad, (r64[3], r32[3]), what="bn dbeta")     # signed sums that cancel: one scale (tests/_tol.py)
     close(col(ours.running_mean), (col(r64[4]), col(r32[4])), what="running_mean")
     close(col(ours.running_var), (col(r64[5]), col(r32[5])), what="running_var")
     assert int(ours.num_batches_tracked) == 1
     ours.eval()                                                    # eval: running statistics, library path
-    close(ours(x.to(dev)), (r64[6], r32[6]), what="bn eval")
+    close(ours(x.to(dev)), (r64[6], r32[6]), what="bn eval", max_ref32_frac=1.0)
 
 
 def test_state_dict_interchanges_with_torch(dev):

@@ -513,4 +513,11 @@ def test_c5_idgin_tf_model_d512_on_ego_batch_of_the_10m_graph(dev, big_graph):
     assert_close_all(loss.reshape(1), loss64.reshape(1), 1e-5, ref32=loss32.reshape(1), what="idgin d=512 loss")
     for k, p in params.items():
         assert p.grad is not None, k
+        if k.endswith(".2.bias") and "mlp_" in k:
+            # the bias of a Dense that feeds a BatchNormalization in training mode has an exactly-zero gradient (the batch
+            # mean removes it): every evaluation returns rounding residue (~1e-19 in float64); it must be negligible
+            # against the gradient of the kernel next to it
+            wk = k[:-len("bias")] + "weight"
+            assert float(p.grad.abs().max()) <= 1e-6 * float(params[wk].grad.abs().max()), k
+            continue
         assert_close_all(p.grad, g64[k], 1e-5, ref32=g32[k], what=f"idgin d=512 grad {k}")

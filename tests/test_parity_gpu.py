@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from _tol import both, close, close_all
+from _tol import both, close, close_all, mag_of
 from oracle import ref_ops as R
 
 pytestmark = pytest.mark.gpu
@@ -234,9 +234,13 @@ def test_aggregation_matches_golden(dev, golden):
             for red in ("sum", "mean", "max"):
                 # float64: the oracle on the golden inputs; float32: the committed golden output itself
                 r64 = both(lambda c: R.coo_aggregate(eic[1], eic[0], None, c(xc), n, red))[0]
-                close(ops.spmm(Gu, x, red), (r64, torch.from_numpy(z[f"{name}/agg_{red}_d{d}"])), what=f"{name} {red} d{d}")
+                mag = None if red == "max" else mag_of(lambda c: R.coo_aggregate(eic[1], eic[0], None, c(xc).abs(), n, red))
+                close(ops.spmm(Gu, x, red), (r64, torch.from_numpy(z[f"{name}/agg_{red}_d{d}"])), what=f"{name} {red} d{d}",
+                      mag=mag)
                 r64 = both(lambda c: R.coo_aggregate(eic[1], eic[0], c(wc), c(xc), n, red))[0]
-                close(ops.spmm(Gw, x, red), (r64, torch.from_numpy(z[f"{name}/aggw_{red}_d{d}"])), what=f"{name} w {red} d{d}")
+                mag = None if red == "max" else mag_of(lambda c: R.coo_aggregate(eic[1], eic[0], c(wc).abs(), c(xc).abs(), n, red))
+                close(ops.spmm(Gw, x, red), (r64, torch.from_numpy(z[f"{name}/aggw_{red}_d{d}"])), what=f"{name} w {red} d{d}",
+                      mag=mag)
 
 
 @pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 63, 64, 96, 100, 128, 130, 256, 260, 512, 1024])
@@ -250,7 +254,10 @@ def test_feature_widths(dev, d):
     x = torch.randn(N, d, generator=g)
     G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev))
     for red in ("sum", "mean", "max"):
-        close(ops.spmm(G, x.to(dev), red), both(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(x), N, red)), what=red)
+        # narrow rows are single signed sums that may cancel: also held against the sum of absolute terms (_tol rule d)
+        mag = None if red == "max" else mag_of(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(x).abs(), N, red))
+        close(ops.spmm(G, x.to(dev), red), both(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(x), N, red)), what=red,
+              mag=mag)
     # a strided view (leading dimension > d) takes the same path
     xp = torch.randn(N, d + 4, generator=g)
     close(ops.spmm(G, xp.to(dev)[:, :d], "sum"), both(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(xp[:, :d]), N, "sum")),
@@ -574,15 +581,19 @@ def test_randomised_graphs_under_a_tiny_plan(dev):
             for ww in (None, w):
                 G = ga.CSRGraph.from_edge_index(ei.to(dev), N, None if ww is None else ww.to(dev))
                 for red in ("sum", "mean", "max"):
+                    mag = None if red == "max" else mag_of(lambda c: R.coo_aggregate(
+                        ei[1], ei[0], None if ww is None else c(ww).abs(), c(x).abs(), N, red))
                     close(ops.spmm(G, x.to(dev), red),
                           both(lambda c: R.coo_aggregate(ei[1], ei[0], None if ww is None else c(ww), c(x), N, red)),
-                          what=f"tiny plan, trial {trial} {red}")
+                          what=f"tiny plan, trial {trial} {red}", mag=mag)
             ids = torch.randperm(N, generator=g)[:max(1, N // 10)]
             G = ga.CSRGraph.from_edge_index(ei.to(dev), N, w.to(dev))
             P, Q = ops.idgnn_aggregate(G, ids.to(dev), x.to(dev))
             sel = torch.zeros(N, 1); sel[ids] = 1
-            close(P, both(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(x), N, "sum")), what=f"tiny plan P, trial {trial}")
-            close(Q, both(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(x * sel), N, "sum")), what=f"tiny plan Q, trial {trial}")
+            close(P, both(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(x), N, "sum")), what=f"tiny plan P, trial {trial}",
+                  mag=mag_of(lambda c: R.coo_aggregate(ei[1], ei[0], c(w).abs(), c(x).abs(), N, "sum")))
+            close(Q, both(lambda c: R.coo_aggregate(ei[1], ei[0], c(w), c(x * sel), N, "sum")), what=f"tiny plan Q, trial {trial}",
+                  mag=mag_of(lambda c: R.coo_aggregate(ei[1], ei[0], c(w).abs(), c(x * sel).abs(), N, "sum")))
     finally:
         ga.CSRGraph.PLAN_CONFIG = None
 
@@ -615,12 +626,19 @@ def test_dense_fused_mfma_kernel(dev, M, F, d, dual):
         o.backward(c(dy))
         return [o.detach()] + [t.grad for t in refs]
     r64, r32 = both(ref)
-    close(out, (r64[0], r32[0]), what="transform forward")
+    # sums of absolute terms (rule d of tests/_tol.py): with F = 1 or d = 1 a "row" is one signed dot product
+    mag_out = P.double().abs() @ W.double().abs() + b.double().abs() + (Q.double().abs() @ Wi.double().abs() if dual else 0)
+    gm = (dy.double() * mask).abs()
+    mags = {"P": gm @ W.double().abs().t(), "Q": gm @ Wi.double().abs().t()}
+    close(out, (r64[0], r32[0]), what="transform forward", mag=mag_out)
     for i, (a, name) in enumerate(zip(args, "P W Q Wid b".split())):
         if not dual and name in ("Q", "Wid"):
             continue
         # input gradients are per row; weight / bias gradients are reductions over all M rows: one scale
-        (close if name in ("P", "Q") else close_all)(a.grad, (r64[1 + i], r32[1 + i]), what=f"transform d{name}")
+        if name in ("P", "Q"):
+            close(a.grad, (r64[1 + i], r32[1 + i]), what=f"transform d{name}", mag=mags[name])
+        else:
+            close_all(a.grad, (r64[1 + i], r32[1 + i]), what=f"transform d{name}")
     # the raw kernel really ran for these shapes (no library fallback)
     assert ops._raw_dense_fused(P.to(dev), W.to(dev), None, None, None, False) is not None
 
@@ -754,7 +772,15 @@ def test_additive_attention_coefficients_in_one_pass(dev, heads):
         return r.detach(), adr.grad, asr.grad
     r64, r32 = both(ref_fn)
     close(alpha, (r64[0], r32[0]), what="additive attention coefficients")
-    close(adg.grad, (r64[1], r32[1]), what="d a_dst")
-    close(asg.grad, (r64[2], r32[2]), what="d a_src")
+    # the gradient of a softmax row sums to zero: d a_dst[i] = sum_e ds_e * lrelu' is a sum that cancels BY CONSTRUCTION
+    # (exactly, when the slope is constant over the row).  Its natural scale is the sum of absolute terms
+    # |alpha_e| (|dalpha_e| + sum_row |alpha dalpha|)  (rule d of tests/_tol.py)
+    al, dl = r64[0], dal.double()
+    rowdot = torch.zeros(N, heads, dtype=torch.float64).index_add_(0, rows, (al * dl).abs())
+    terms = al.abs() * (dl.abs() + rowdot[rows])
+    mag_dst = torch.zeros(N, heads, dtype=torch.float64).index_add_(0, rows, terms)
+    mag_src = torch.zeros(N, heads, dtype=torch.float64).index_add_(0, cols, terms)
+    close(adg.grad, (r64[1], r32[1]), what="d a_dst", mag=torch.maximum(mag_dst, r64[1].abs()))
+    close(asg.grad, (r64[2], r32[2]), what="d a_src", mag=torch.maximum(mag_src, r64[2].abs()))
     sums = torch.zeros(N, heads, dtype=torch.float64).index_add_(0, rows, alpha.detach().cpu().double())
     assert float((sums - 1.0).abs().max()) <= 1e-5                  # every row has its self loop: coefficients sum to 1
