@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmpengine.so")
+LIB_PATH = os.environ.get("MP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "libmpengine.so")   # (MP_ENGINE_LIB: a variant build, for A/B studies)
 
 MP_OK = 0
 SUM, MEAN, MAX = 0, 1, 2

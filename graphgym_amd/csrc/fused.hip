@@ -53,6 +53,14 @@ struct FusedArgs {
 };
 
 constexpr int kTileRows = 32;
+// -DMP_FUSED_TIMING: s_memtime stamps of the phases of sampled tiles (one tile in 128), read back with mp_debug_read by
+// scripts/dbg/fused_phases.py — how profiles/r03_fused_phases.json was made.  Not part of the product build.
+#ifdef MP_FUSED_TIMING
+__device__ long long g_dbg[1 << 18];
+#define DBG_T(slot) do { if (dbg_on && lane == 0) g_dbg[dbg_base + wave * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DBG_T(slot) do {} while (0)
+#endif
 #ifndef MP_FUSED_U
 #define MP_FUSED_U 16   // neighbour rows in flight per wave in phase A
 #endif
@@ -159,7 +167,8 @@ __device__ __forceinline__ void mfma_half_bf16x3(const float (*T)[FH + 4], const
 
 // W: floats per lane of one K half (half width FH = 64 W); KH: K halves (F = KH * FH); NCB: output column blocks of
 // 256 whose accumulators stay live across the halves (KH == 2 only; KH == 1 walks the blocks one after another);
-// PF: W fragments fetched PF K-groups ahead; NT_OUT: non-temporal stores of out
+// PF: W fragments fetched PF K-groups ahead; NT_OUT: non-temporal stores of out (on: -0.3 % in an
+// in-process A/B, scripts/dbg/fused_ab.py)
 template <int W, bool WEIGHTED, int U, int KH, int NCB, int PF, bool NT_OUT, bool BF16X3>
 __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(FusedArgs a) {
   constexpr int FH = kWave * W;
@@ -175,6 +184,11 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int R0 = blockIdx.x * kTileRows;
   const int R1 = min(R0 + kTileRows, a.N);
+#ifdef MP_FUSED_TIMING
+  const bool dbg_on = (blockIdx.x % 128) == 7 && blockIdx.x / 128 < 2048;
+  const int dbg_base = (blockIdx.x / 128) * 64;
+#endif
+  DBG_T(0);
 
   // ---- the wave's run of entries (the same for every K half) ----
   // lane i (<= 32) holds the start of tile row i (rows past the end of the matrix are empty)
@@ -284,7 +298,9 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
         *reinterpret_cast<f32x4*>(&T[m][c]) = v;
       }
     }
+    DBG_T(1);
     __syncthreads();   // T initialised (and carry_row / inv_deg / defer_l visible)
+    DBG_T(2);
 
     // ---- phase A: this wave's run of entries, feature columns [k0, k0 + FH) ----
     if (es < ee) {
@@ -340,7 +356,9 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
       }
       flush();
     }
+    DBG_T(3);
     __syncthreads();
+    DBG_T(4);
 
     // ---- carries: a row cut by run boundaries gets its later parts in wave order ----
     if (tid < FH) {
@@ -364,6 +382,7 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
       }
     }
 
+    DBG_T(5);
     // ---- phase B: [32 x FH] tile x W[k0 : k0 + FH, :] on the matrix cores ----
     if constexpr (KH == 1) {
       for (int cb = 0; cb < a.dout; cb += 64 * kWavesPerBlock) {
@@ -381,7 +400,9 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
           const float* __restrict__ wp = a.Wm + (int64_t)(4 * kk) * a.ldw + ccol;
           mfma_half<FH, PF>(T, wp, a.ldw, acc0, acc1, fr, kk);
         }
+        DBG_T(6);
         store_block(acc0, acc1, n0);
+        DBG_T(7);
       }
     } else {
 #pragma unroll
@@ -415,11 +436,11 @@ template <int W, int KH, int NCB, int PF>
 static int launch_fused(const FusedArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)ceil_div(a.N, kTileRows)), block(kBlock);
   if (a.Wsp != nullptr) {
-    if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, MP_FUSED_U, KH, NCB, PF, false, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((agg_dense_kernel<W, false, MP_FUSED_U, KH, NCB, PF, false, true>), grid, block, 0, st, a);
+    if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((agg_dense_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, true>), grid, block, 0, st, a);
   } else {
-    if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, MP_FUSED_U, KH, NCB, PF, false, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((agg_dense_kernel<W, false, MP_FUSED_U, KH, NCB, PF, false, false>), grid, block, 0, st, a);
+    if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((agg_dense_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, false>), grid, block, 0, st, a);
   }
   MP_LAUNCH_CHECK();
   return MP_OK;
@@ -463,6 +484,12 @@ __global__ __launch_bounds__(kBlock) void id_fixup_kernel(const int32_t* __restr
 using namespace mp;
 
 extern "C" {
+
+#ifdef MP_FUSED_TIMING
+int mp_debug_read(void* dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mp::g_dbg), bytes) == hipSuccess ? 0 : 4;
+}
+#endif
 
 static int agg_dense_common(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
                             const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale,

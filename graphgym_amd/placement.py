@@ -22,7 +22,7 @@ conflict map).  It placed as well but took memory torch could not see or reclaim
 reused ranges without stream tracking; it is gone.
 
 Environment: MP_PLACEMENT=off disables the check; MP_PLACE_MIN_MB the size from which outputs are checked (default
-1024: smaller ones live in L2 / Infinity Cache); MP_PLACE_TRIES the candidates per allocation (default 4);
+1024: smaller ones live in L2 / Infinity Cache); MP_PLACE_TRIES the candidates per allocation (default 6);
 MP_PLACE_ACCEPT the accepted slow-down of the probe against the fastest probe seen (default 0.05: good positions
 measure +0-4 %, conflicting ones +6-12 %).
 """
@@ -39,7 +39,7 @@ MiB = 1 << 20
 CHUNK = 256 * MiB                         # bytes of the candidate written per probe (reads: FAN x as much, past every cache)
 FAN = 10                                  # rows read per row written: the mean degree of the path's graphs
 MIN_BYTES = int(os.environ.get("MP_PLACE_MIN_MB", "1024")) * MiB
-TRIES = int(os.environ.get("MP_PLACE_TRIES", "4"))
+TRIES = int(os.environ.get("MP_PLACE_TRIES", "6"))
 ACCEPT = float(os.environ.get("MP_PLACE_ACCEPT", "0.05"))
 MEMO_ENTRIES = 4096
 
