@@ -182,11 +182,16 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int R0 = blockIdx.x * kTileRows;
+  // A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (kFusedMaxGrid workgroups at most: ~5 tiles each at
+  // 10^7 rows).  Fewer, longer-lived workgroups: -1.7 % (out only) / -4 % (aggregated rows kept) against one workgroup
+  // per tile in an in-process A/B; a smaller grid loses to the hub tiles at the head of the matrix (1024 workgroups:
+  // +14 %).  Tiles are independent and a tile's summation order does not depend on who computes it: same bits.
+  for (int tile = blockIdx.x; (int64_t)tile * kTileRows < a.N; tile += gridDim.x) {
+  const int R0 = tile * kTileRows;
   const int R1 = min(R0 + kTileRows, a.N);
 #ifdef MP_FUSED_TIMING
-  const bool dbg_on = (blockIdx.x % 128) == 7 && blockIdx.x / 128 < 2048;
-  const int dbg_base = (blockIdx.x / 128) * 64;
+  const bool dbg_on = (tile % 128) == 7 && tile / 128 < 2048;
+  const int dbg_base = (tile / 128) * 64;
 #endif
   DBG_T(0);
 
@@ -430,11 +435,16 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
       if (n0 < a.dout) store_block(acc[b][0], acc[b][1], n0);
     }
   }
+  __syncthreads();   // every wave is done with T, carry_row, inv_deg before the next tile rewrites them
+  }
 }
+
+constexpr int kFusedMaxGrid = 65536;
 
 template <int W, int KH, int NCB, int PF>
 static int launch_fused(const FusedArgs& a, hipStream_t st) {
-  const dim3 grid((unsigned)ceil_div(a.N, kTileRows)), block(kBlock);
+  const int64_t n_tiles = ceil_div(a.N, kTileRows);
+  const dim3 grid((unsigned)(n_tiles < kFusedMaxGrid ? n_tiles : kFusedMaxGrid)), block(kBlock);
   if (a.Wsp != nullptr) {
     if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((agg_dense_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, true>), grid, block, 0, st, a);

@@ -34,7 +34,7 @@ def _op_bn_fwd_raw(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], 
     _require_hip(x, "x")
     x = x if (x.dtype == torch.float32 and x.stride(-1) == 1) else x.float().contiguous()
     N, d = x.shape
-    y = placement.empty_or_torch((N, d), x.device, reads=(x,))
+    y = placement.empty_or_torch((N, d), x.device, reads=(x,), streaming=True)
     mean = torch.empty(d, dtype=torch.float32, device=x.device)
     invstd = torch.empty_like(mean)
     var_u = torch.empty_like(mean)
@@ -64,7 +64,7 @@ def _op_bn_bwd_raw(dy: Tensor, y: Optional[Tensor], x: Tensor, weight: Optional[
     x = x if (x.dtype == torch.float32 and x.stride(-1) == 1) else x.float().contiguous()
     N, d = x.shape
     dy = dy.contiguous()
-    dx = placement.empty_or_torch((N, d), x.device, reads=(dy, x))
+    dx = placement.empty_or_torch((N, d), x.device, reads=(dy, x), streaming=True)
     dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
     dbeta = torch.empty_like(dgamma)
     w = None if weight is None else weight.detach().contiguous()

@@ -89,7 +89,7 @@ def _raw_dense_fused(P, W, Q, W_id, bias, relu):
     d = W.size(1)
     if Q is None and dense_x3_supported(P, F, d):
         return _raw_dense_x3(P, W, bias, relu)
-    out = placement.empty_or_torch((M, d), P.device, reads=(P, Q))
+    out = placement.empty_or_torch((M, d), P.device, reads=(P, Q), streaming=True)
     Wc = W.contiguous()
     Wi = None if W_id is None else W_id.contiguous()
     b = None if bias is None else bias.contiguous()
@@ -138,7 +138,7 @@ def _raw_dense_x3(P, W, bias=None, relu=False, trans=False, out=None):
     n = W.size(0) if trans else W.size(1)
     sp = _split_w(W, trans)
     if out is None:
-        out = placement.empty_or_torch((M, n), P.device, reads=(P,))
+        out = placement.empty_or_torch((M, n), P.device, reads=(P,), streaming=True)
     b = None if bias is None else bias.detach().contiguous()
     if b is not None and b.data_ptr() % 16:
         b = b.clone()                        # a slice of a longer bias: the kernel reads it in 16-byte groups
@@ -242,7 +242,7 @@ def _raw_dense_wgrad_relu(P, G, Y, want_bias=False, want_gm=True, gm_out=None):
     # the masked gradient is written only when an input-gradient launch will read it (a first layer has none)
     # (gm_out: a [M, d] view to receive it, e.g. one half of a concatenated gradient)
     gm = gm_out if gm_out is not None else (
-        placement.empty_or_torch((M, d), P.device, reads=(G, Y, P)) if want_gm else None)
+        placement.empty_or_torch((M, d), P.device, reads=(G, Y, P), streaming=True) if want_gm else None)
     with torch.cuda.device(P.device):
         nb = C.c_size_t(0)
         check(L.mp_dense_wgrad_ws_bytes(M, F, d, C.byref(nb)))
@@ -293,7 +293,7 @@ class _ConcatDense(torch.autograd.Function):
     def forward(ctx, x, m, Ws, Wn, bias, relu):
         x, m = _f32c(x, "x"), _f32c(m, "m")
         ku, kn = Ws.size(1), Wn.size(1)
-        out = placement.empty_or_torch((x.size(0), ku + kn), x.device, reads=(x, m))
+        out = placement.empty_or_torch((x.size(0), ku + kn), x.device, reads=(x, m), streaming=True)
         b = None if bias is None else bias.detach()
         _dense_into(out[:, :ku], x, Ws.detach(), None if b is None else b[:ku], relu)
         _dense_into(out[:, ku:], m, Wn.detach(), None if b is None else b[ku:], relu)
@@ -311,7 +311,7 @@ class _ConcatDense(torch.autograd.Function):
         if ctx.relu and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
             # the ReLU mask rides in the two weight-gradient passes (one per half of the output); the masked halves are
             # written only when an input gradient will read them (a first layer has none)
-            mg = placement.empty_or_torch(tuple(g.shape), g.device, reads=(g, out)) if need_in else None
+            mg = placement.empty_or_torch(tuple(g.shape), g.device, reads=(g, out), streaming=True) if need_in else None
             rs = _raw_dense_wgrad_relu(x, g[:, :ku], out[:, :ku], want_bias=ctx.has_bias, want_gm=need_in,
                                        gm_out=None if mg is None else mg[:, :ku])
             rn = None if rs is None else _raw_dense_wgrad_relu(m, g[:, ku:], out[:, ku:], want_bias=ctx.has_bias,
@@ -363,7 +363,7 @@ class _SageConcatFused(torch.autograd.Function):
             # the ReLU mask rides in the two weight-gradient passes (one per half of the concatenated output), which
             # also leave the masked halves in one buffer for the input-gradient launches: no threshold_backward pass
             need_gm = ctx.needs_input_grad[0]
-            mg = placement.empty_or_torch(tuple(gm.shape), gm.device, reads=(gm, out)) if need_gm else None
+            mg = placement.empty_or_torch(tuple(gm.shape), gm.device, reads=(gm, out), streaming=True) if need_gm else None
             rs = _raw_dense_wgrad_relu(x, gm[:, :ku], out[:, :ku], want_bias=ctx.has_bias, want_gm=need_gm,
                                        gm_out=None if mg is None else mg[:, :ku])
             rn = None if rs is None else _raw_dense_wgrad_relu(P, gm[:, ku:], out[:, ku:], want_bias=ctx.has_bias,

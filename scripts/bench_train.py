@@ -41,8 +41,10 @@ def run(kind, n, d, steps, rank, world, dev, ego_centres=0, radius=2):
     def fl():
         inputs = [x, ei] + ([ids] if model.with_id else [])
         return H.tfg_loss(model(inputs, holder=holder), label_index, labels, model.kernel_parameters())
-    for _ in range(2):
+    from graphgym_amd import placement
+    for _ in range(int(os.environ.get("WARM", "2"))):
         H.train_step(model, opt, fl, bucket)
+    st0 = placement.stats(dev) if placement.enabled() else {}
     D.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         H.train_step(model, opt, fl, bucket)
@@ -53,7 +55,11 @@ def run(kind, n, d, steps, rank, world, dev, ego_centres=0, radius=2):
         print(json.dumps({"what": f"{kind} training step", "n_gpus": world, "nodes_per_gpu": n_nodes,
                           "edges_per_gpu": int(ei.size(1)), "d": d, "conv_layers": len(model.convs), "ms_per_step": dt * 1e3,
                           "edges_per_s_fwd_bwd_all_layers": 2 * len(model.convs) * edges / dt,
-                          "ego_batch_build_ms": t_ego * 1e3, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+                          "ego_batch_build_ms": t_ego * 1e3, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9,
+                          "reserved_GB": torch.cuda.memory_reserved() / 1e9,
+                          "placement_in_timed_steps": {k: (placement.stats(dev)[k] - st0[k]) for k in
+                                                       ("allocations", "probed_pairs", "memo_hits", "retries")} if st0 else None}),
+              flush=True)
     del model, opt, x, ei
     torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
 
