@@ -28,6 +28,7 @@
 // (`defer_act`), and id_fixup_kernel adds A_id Z to exactly those rows and applies the activation.
 #include "common.h"
 #include "vecio.h"
+#include <atomic>
 #include <limits.h>
 #include <type_traits>
 
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
   // 10^7 rows).  Fewer, longer-lived workgroups: -1.7 % (out only) / -4 % (aggregated rows kept) against one workgroup
   // per tile in an in-process A/B; a smaller grid loses to the hub tiles at the head of the matrix (1024 workgroups:
   // +14 %).  Tiles are independent and a tile's summation order does not depend on who computes it: same bits.
+  // (KH == 2 — F = 512 — keeps one tile per workgroup: with the tile loop its 164 registers spill)
   for (int tile = blockIdx.x; (int64_t)tile * kTileRows < a.N; tile += gridDim.x) {
   const int R0 = tile * kTileRows;
   const int R1 = min(R0 + kTileRows, a.N);
@@ -435,16 +437,359 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
       if (n0 < a.dout) store_block(acc[b][0], acc[b][1], n0);
     }
   }
+  if constexpr (KH == 2) break;
   __syncthreads();   // every wave is done with T, carry_row, inv_deg before the next tile rewrites them
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same layer with the two phases on DIFFERENT waves (round 3).  Measured on the kernel above
+// (profiles/r03_fused_phases.json): a workgroup gathers only 60 % of its time — phase B is 24 % (its W fragments are L2
+// hits, but the vector memory path returns in order, so behind the gathers of the CU's other waves each of the 16
+// fetch rounds costs ~1 us), the head of the tile and the output store 6 % each — and with four workgroups per CU
+// there are moments when too few of them gather.  Here a workgroup is 8 waves walking tiles it draws from a counter:
+//   waves 0-3 (producers): initialise tile buffer b, gather their runs into it, add the carries        — item j
+//   waves 4-7 (consumers): store the aggregated rows, multiply buffer b^1 by W, store the output       — item j - 1
+// An item is one K half of one tile; the two roles meet at three workgroup barriers per item (tile initialised /
+// runs reduced / carries added), and the consumers reach each of them long before the producers, so the gathers of a
+// workgroup never stop for a product or a store.  Two buffers: 2 x 33 KiB of LDS, two workgroups (16 waves) per CU,
+// 8 of them gathering all the time — the plan-based kernel runs at full speed with 8 waves per CU
+// (profiles/r03_occupancy_sweep.jsonl).  Tiles come from an atomic counter in ascending order, so the hub tiles at the
+// head of the matrix start first and a workgroup that holds one simply draws fewer tiles; which workgroup computes a
+// tile does not enter its arithmetic: same bits as the kernel above.
+constexpr int kPcThreads = 512;
+constexpr int kPcGather = 4;      // producer waves (and consumer waves) per workgroup
+
+template <int W, bool WEIGHTED, int U, int KH, int NCB, int PF, bool NT_OUT, bool BF16X3>
+__global__ __launch_bounds__(kPcThreads, 4) void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr,
+                                                                     int32_t n_tiles) {
+  constexpr int FH = kWave * W;
+  constexpr int LDT = FH + 4;
+  __shared__ __attribute__((aligned(16))) float T[2][kTileRows][LDT];
+  __shared__ __attribute__((aligned(16))) float carry[kPcGather - 1][FH];
+  __shared__ int carry_row[kPcGather];
+  __shared__ float inv_deg[2][kTileRows];
+  __shared__ int defer_l[2][kTileRows];
+  __shared__ int next_tile_s, next2_tile_s;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave < kPcGather;
+  const int cw = wave - kPcGather;            // consumer wave: owns output columns [64 cw, 64 cw + 64) of every block
+  const int fr = lane & 31, kk = lane >> 5;
+  const int fr_c = fr, kk_c = kk;
+
+  // items are drawn TWO ahead: `cur` is gathered, `nxt` is known (its row starts are requested while `cur` is gathered)
+  if (tid == 0) {
+    next_tile_s = (int)atomicAdd(tile_ctr, 1u);
+    if (KH == 1) next2_tile_s = (int)atomicAdd(tile_ctr, 1u);
+  }
+  __syncthreads();
+  int cur_tile = next_tile_s < n_tiles ? next_tile_s : -1;
+  int cur_kh = 0;
+  int nxt_tile = KH == 1 ? (next2_tile_s < n_tiles ? next2_tile_s : -1) : cur_tile;
+  int nxt_kh = KH == 1 ? 0 : 1;
+  int prev_tile = -1, prev_kh = 0;            // the item the consumers work on
+  int buf = 0;
+  const bool has_s = a.S != nullptr;          // the self term initialises the tile (GIN's (1 + eps) x): one more barrier
+
+  // producer state of the current tile (the same for every K half)
+  int rp_v = INT_MAX, rp_nxt = INT_MAX, es = 0, ee = 0, first_rl = -1;
+  bool cont = false;
+  if (producer && cur_tile >= 0)
+    rp_nxt = lane <= kTileRows ? a.rowptr[min(cur_tile * kTileRows + lane, min(cur_tile * kTileRows + kTileRows, a.N))] : INT_MAX;
+  // consumer accumulators (KH == 2: live across the two halves of a tile)
+  f32x16 acc[KH == 2 ? NCB : 1][2];
+
+  while (cur_tile >= 0 || prev_tile >= 0) {
+    const int R0 = cur_tile * kTileRows;
+    const int R1 = min(R0 + kTileRows, a.N);
+    const int k0 = cur_kh * FH;
+    // ================= producers: set up (cur_tile, cur_kh) in buffer `buf` =================
+    if (producer && cur_tile >= 0) {
+      if (cur_kh == 0) {
+        rp_v = rp_nxt;                         // requested one item ago: the load does not wait behind this CU's gathers
+        if (wave == 0) {
+          const int nxt = __shfl_down(rp_v, 1, kWave);
+          if (lane < kTileRows) {
+            inv_deg[buf][lane] = (a.mean && nxt > rp_v) ? 1.0f / (float)(nxt - rp_v) : (a.mean ? 0.f : 1.f);
+            defer_l[buf][lane] = (a.defer_act != nullptr && R0 + lane < R1) ? (int)a.defer_act[R0 + lane] : 0;
+          }
+        }
+        const int E0 = bcast_i(rp_v, 0);
+        const int E1 = bcast_i(rp_v, kTileRows);
+        const int q = (E1 - E0 + kPcGather - 1) / kPcGather;
+        es = min(E0 + wave * q, E1);
+        ee = min(es + q, E1);
+        first_rl = -1;
+        cont = false;
+        if (es < ee) {
+          const unsigned long long started = __ballot(lane >= 1 && lane <= kTileRows && rp_v <= es);
+          first_rl = __builtin_amdgcn_readfirstlane((int)__popcll(started));
+          cont = bcast_i(rp_v, first_rl) < es;
+        }
+      } else if (wave == 0 && lane < kTileRows) {      // second half: the tile's scales move to this buffer
+        inv_deg[buf][lane] = inv_deg[buf ^ 1][lane];
+        defer_l[buf][lane] = defer_l[buf ^ 1][lane];
+      }
+      if (lane == 0) carry_row[wave] = cont ? first_rl : -1;
+      if (has_s) {
+        constexpr int VPR = FH / 4;
+        for (int i = tid; i < kTileRows * VPR; i += kPcGather * kWave) {
+          const int m = i / VPR, c = (i % VPR) * 4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (R0 + m < R1) {
+            v = *reinterpret_cast<const f32x4*>(a.S + (int64_t)(R0 + m) * a.lds + k0 + c);
+            v *= a.self_scale;
+          }
+          *reinterpret_cast<f32x4*>(&T[buf][m][c]) = v;
+        }
+      }
+    }
+    if (producer && nxt_tile >= 0 && nxt_kh == 0) {   // the next tile's row starts, one item ahead
+      const int NR0 = nxt_tile * kTileRows;
+      rp_nxt = lane <= kTileRows ? a.rowptr[min(NR0 + lane, min(NR0 + kTileRows, a.N))] : INT_MAX;
+    }
+    if (has_s) __syncthreads();   // b0 (self term only): buffer `buf` initialised before the runs add into it
+
+    if (producer) {
+      // ================= producers: phase A of (cur_tile, cur_kh) =================
+      if (cur_tile >= 0 && !has_s && wave == 0 && bcast_i(rp_v, 0) == bcast_i(rp_v, kTileRows)) {
+        float z[W];                                      // a tile without a single entry
+#pragma unroll
+        for (int k = 0; k < W; ++k) z[k] = 0.f;
+        for (int r = 0; r < kTileRows; ++r) store_vec<W>(&T[buf][r][lane * W], z);
+      }
+      if (cur_tile >= 0 && es < ee) {
+        const float* __restrict__ xlane = a.X + k0 + lane * W;
+        int rl = first_rl;
+        int rend = bcast_i(rp_v, rl + 1);
+        float accr[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) accr[k] = 0.f;
+        // Without a self term nothing initialises the tile: the wave in whose run a row STARTS stores the row (also a
+        // row without entries it passes over), later parts of a cut row go to the carries, and the rows no run passes
+        // over — empty rows in front of a run's first entry, and behind the tile's last entry — are zeroed by that run.
+        auto flush = [&]() {
+          if (cont && rl == first_rl) {
+            store_vec<W>(&carry[wave - 1][lane * W], accr);
+          } else if (has_s) {
+            float t[W];
+            load_vec<W>(&T[buf][rl][lane * W], t);
+#pragma unroll
+            for (int k = 0; k < W; ++k) t[k] += accr[k];
+            store_vec<W>(&T[buf][rl][lane * W], t);
+          } else {
+            store_vec<W>(&T[buf][rl][lane * W], accr);
+          }
+#pragma unroll
+          for (int k = 0; k < W; ++k) accr[k] = 0.f;
+        };
+        if (!has_s) {   // the empty rows between the previous run's last entry (or the tile's head) and this run's first
+          int lo = 0;
+          if (es > bcast_i(rp_v, 0)) {
+            const unsigned long long before = __ballot(lane >= 1 && lane <= kTileRows && rp_v <= es - 1);
+            lo = __builtin_amdgcn_readfirstlane((int)__popcll(before)) + 1;
+          }
+          float z[W];
+#pragma unroll
+          for (int k = 0; k < W; ++k) z[k] = 0.f;
+          for (int r = lo; r < first_rl; ++r) store_vec<W>(&T[buf][r][lane * W], z);
+        }
+        for (int ec = es; ec < ee; ec += kWave) {
+          const int me = min(ec + lane, ee - 1);
+          const int cv = a.col[me] & 0x7fffffff;   // an identity mark (sign bit) is not part of the index
+          float wv = 1.f;
+          if (WEIGHTED) wv = a.val[me];
+          const int n = min(kWave, ee - ec);
+          for (int jb = 0; jb < n; jb += U) {
+            float v[U][W];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+              const int c = bcast_i(cv, jb + j);
+              load_vec<W>(xlane + (int64_t)c * a.ldx, v[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+              const int e = ec + jb + j;
+              if (e < ee) {
+                while (e >= rend) {
+                  flush();
+                  rl += 1;
+                  rend = bcast_i(rp_v, rl + 1);
+                }
+                const float w = WEIGHTED ? bcast_f(wv, jb + j) : 1.f;
+#pragma unroll
+                for (int k = 0; k < W; ++k) accr[k] = fmaf(w, v[j][k], accr[k]);
+              }
+            }
+          }
+        }
+        flush();
+        if (!has_s && ee == bcast_i(rp_v, kTileRows)) {   // this run closes the tile: the empty rows behind it
+          float z[W];
+#pragma unroll
+          for (int k = 0; k < W; ++k) z[k] = 0.f;
+          for (int r = rl + 1; r < kTileRows; ++r) store_vec<W>(&T[buf][r][lane * W], z);
+        }
+      }
+    } else if (prev_tile >= 0) {
+      // ================= consumers: (prev_tile, prev_kh) from buffer buf ^ 1 =================
+      const int pb = buf ^ 1;
+      const int PR0 = prev_tile * kTileRows;
+      const int PR1 = min(PR0 + kTileRows, a.N);
+      const int pk0 = prev_kh * FH;
+      const int ctid = tid - kPcGather * kWave;
+      if (a.P != nullptr) {   // the aggregated rows, kept for the weight gradient
+        constexpr int VPR = FH / 4;
+        for (int i = ctid; i < kTileRows * VPR; i += kPcGather * kWave) {
+          const int m = i / VPR, c = (i % VPR) * 4;
+          if (PR0 + m < PR1) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(&T[pb][m][c]);
+            v *= inv_deg[pb][m];
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.P + (int64_t)(PR0 + m) * a.ldp + pk0 + c));
+          }
+        }
+      }
+      auto store_block = [&](const f32x16& acc0, const f32x16& acc1, int n0) {
+        int fr = fr_c, kk = kk_c;   // (re-derived behind the accumulators: see the kernel above)
+        asm volatile("" : "+v"(fr), "+v"(kk) : "v"(acc0[0]), "v"(acc1[15]));
+        const int cpair = n0 + 2 * fr;
+        const bool col_ok = cpair < a.dout;
+        f32x2 bv = {0.f, 0.f};
+        if (a.bias != nullptr && col_ok) bv = *reinterpret_cast<const f32x2*>(a.bias + cpair);
+        auto finish = [&](int r, int rl) {
+          const float sc = inv_deg[pb][rl];
+          f32x2 o = {fmaf(acc0[r], sc, bv[0]), fmaf(acc1[r], sc, bv[1])};
+          if (a.R != nullptr && col_ok && PR0 + rl < PR1) {
+            const f32x2 rv = *reinterpret_cast<const f32x2*>(a.R + (int64_t)(PR0 + rl) * a.ldr + cpair);
+            o[0] += rv[0]; o[1] += rv[1];
+          }
+          if (a.act == MP_ACT_RELU && !defer_l[pb][rl]) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); }
+          return o;
+        };
+        if (a.out_vec4) {
+          const bool odd = fr & 1;
+          const int c4 = n0 + 2 * (fr & ~1);
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * kk;       // rows rl, rl + 1
+            const f32x2 m0 = finish(r, rl), m1 = finish(r + 1, rl + 1);
+            const f32x2 send = odd ? m0 : m1;
+            f32x2 recv;
+            recv[0] = __shfl_xor(send[0], 1, kWave);
+            recv[1] = __shfl_xor(send[1], 1, kWave);
+            const f32x4 o4 = odd ? f32x4{recv[0], recv[1], m1[0], m1[1]} : f32x4{m0[0], m0[1], recv[0], recv[1]};
+            const int row = PR0 + rl + (odd ? 1 : 0);
+            if (row < PR1) {
+              float* dst = a.out + (int64_t)row * a.ldo + c4;
+              if (c4 + 3 < a.dout) {
+                if constexpr (NT_OUT) __builtin_nontemporal_store(o4, reinterpret_cast<f32x4*>(dst));
+                else *reinterpret_cast<f32x4*>(dst) = o4;
+              } else if (c4 < a.dout) {
+                *reinterpret_cast<f32x2*>(dst) = f32x2{o4[0], o4[1]};
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int row = PR0 + rl;
+            const f32x2 o = finish(r, rl);
+            if (col_ok && row < PR1) *reinterpret_cast<f32x2*>(a.out + (int64_t)row * a.ldo + cpair) = o;
+          }
+        }
+      };
+      if constexpr (KH == 1) {
+        for (int cb = 0; cb < a.dout; cb += 64 * kPcGather) {
+          const int n0 = cb + cw * 64;
+          if (n0 >= a.dout) break;                       // wave-uniform
+          const int cpair = n0 + 2 * fr;
+          const int ccol = cpair < a.dout ? cpair : a.dout - 2;
+          f32x16 acc0, acc1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+          if constexpr (BF16X3) {
+            const __bf16* w0 = a.Wsp + ((int64_t)kk * a.dout + ccol) * 8;
+            mfma_half_bf16x3<FH>(T[pb], w0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, acc0, acc1, fr, kk);
+          } else {
+            const float* __restrict__ wp = a.Wm + (int64_t)(4 * kk) * a.ldw + ccol;
+            mfma_half<FH, PF>(T[pb], wp, a.ldw, acc0, acc1, fr, kk);
+          }
+          store_block(acc0, acc1, n0);
+        }
+      } else {
+        if (prev_kh == 0) {
+#pragma unroll
+          for (int b = 0; b < NCB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[b][0][r] = 0.f; acc[b][1][r] = 0.f; }
+        }
+#pragma unroll
+        for (int b = 0; b < NCB; ++b) {
+          const int n0 = b * 64 * kPcGather + cw * 64;
+          if (n0 < a.dout) {                             // wave-uniform
+            const int cpair = n0 + 2 * fr;
+            const int ccol = cpair < a.dout ? cpair : a.dout - 2;
+            if constexpr (BF16X3) {
+              const __bf16* w0 = a.Wsp + ((int64_t)(pk0 / 8 + kk) * a.dout + ccol) * 8;
+              mfma_half_bf16x3<FH>(T[pb], w0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, acc[b][0], acc[b][1], fr, kk);
+            } else {
+              const float* __restrict__ wp = a.Wm + (int64_t)(pk0 + 4 * kk) * a.ldw + ccol;
+              mfma_half<FH, PF>(T[pb], wp, a.ldw, acc[b][0], acc[b][1], fr, kk);
+            }
+          }
+        }
+        if (prev_kh == KH - 1) {
+#pragma unroll
+          for (int b = 0; b < NCB; ++b) {
+            const int n0 = b * 64 * kPcGather + cw * 64;
+            if (n0 < a.dout) store_block(acc[b][0], acc[b][1], n0);
+          }
+        }
+      }
+    }
+    __syncthreads();   // b1: every producer run is reduced into `buf` (and the consumers are done with buf ^ 1)
+
+    // ---- carries: a row cut by run boundaries gets its later parts in wave order ----
+    if (producer && cur_tile >= 0 && tid < FH) {
+#pragma unroll
+      for (int w = 1; w < kPcGather; ++w) {
+        const int cr = carry_row[w];
+        if (cr >= 0) T[buf][cr][tid] += carry[w - 1][tid];
+      }
+    }
+    // the item after `nxt` opens a new tile when `nxt` is a last half: it is drawn here and published by b2
+    const bool draw = nxt_tile >= 0 && nxt_kh == KH - 1;
+    if (tid == kPcThreads - 1 && draw) next_tile_s = (int)atomicAdd(tile_ctr, 1u);
+    __syncthreads();   // b2: buffer `buf` complete; next_tile_s published
+
+    prev_tile = cur_tile; prev_kh = cur_kh;
+    cur_tile = nxt_tile; cur_kh = nxt_kh;
+    if (nxt_tile >= 0) {
+      if (nxt_kh + 1 < KH) {
+        nxt_kh += 1;
+      } else {
+        nxt_kh = 0;
+        nxt_tile = next_tile_s < n_tiles ? next_tile_s : -1;
+      }
+    }
+    buf ^= 1;
+  }
+}
+
+constexpr int kPcSlots = 64;
+constexpr int kMaxDevPc = 16;
+__device__ unsigned int g_pc_tile_ctr[kPcSlots];
+
 constexpr int kFusedMaxGrid = 65536;
 
 template <int W, int KH, int NCB, int PF>
-static int launch_fused(const FusedArgs& a, hipStream_t st) {
+static int launch_fused_tiles(const FusedArgs& a, hipStream_t st) {   // one workgroup walks tiles b, b + grid, ... (round 2 form)
   const int64_t n_tiles = ceil_div(a.N, kTileRows);
-  const dim3 grid((unsigned)(n_tiles < kFusedMaxGrid ? n_tiles : kFusedMaxGrid)), block(kBlock);
+  const dim3 grid((unsigned)(KH == 2 || n_tiles < kFusedMaxGrid ? n_tiles : kFusedMaxGrid)), block(kBlock);
   if (a.Wsp != nullptr) {
     if (a.val) hipLaunchKernelGGL((agg_dense_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((agg_dense_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, true>), grid, block, 0, st, a);
@@ -454,6 +799,52 @@ static int launch_fused(const FusedArgs& a, hipStream_t st) {
   }
   MP_LAUNCH_CHECK();
   return MP_OK;
+}
+
+// the tile counter of one launch: a slot of a small device array, zeroed on the launch's stream right before it.  Slots
+// go round: two launches share one only if more than kPcSlots are in flight at once on different streams.
+static int pc_counter(unsigned int** ctr, hipStream_t st) {
+  static std::atomic<unsigned> next_slot{0};
+  static unsigned int* base[kMaxDevPc] = {nullptr};
+  int dev = 0;
+  MP_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevPc) return MP_ERR_UNSUPPORTED;
+  if (!base[dev]) {
+    void* p = nullptr;
+    MP_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_pc_tile_ctr)));
+    base[dev] = reinterpret_cast<unsigned int*>(p);
+  }
+  *ctr = base[dev] + next_slot.fetch_add(1) % kPcSlots;
+  MP_HIP(hipMemsetAsync(*ctr, 0, sizeof(unsigned int), st));
+  return MP_OK;
+}
+
+template <int W, int KH, int NCB, int PF>
+static int launch_fused(const FusedArgs& a, hipStream_t st) {
+#ifdef MP_FUSED_TILES   // (A/B builds: the round-2 kernel)
+  return launch_fused_tiles<W, KH, NCB, PF>(a, st);
+#endif
+  // F = 512 stays on the one-role kernel: the consumer of the two-role kernel would need the accumulators of two
+  // column blocks (64 registers) beside its W fragments inside 128 registers and spills (81 ms against 57.8 ms)
+  if constexpr (KH == 2) {
+    return launch_fused_tiles<W, KH, NCB, PF>(a, st);
+  } else {
+  const int64_t n_tiles = ceil_div(a.N, kTileRows);
+  unsigned int* ctr = nullptr;
+  const int rc = pc_counter(&ctr, st);
+  if (rc != MP_OK) return rc;
+  const dim3 grid((unsigned)(n_tiles < 2 * kNumCU ? n_tiles : 2 * kNumCU)), block(kPcThreads);
+  const int32_t nt = (int32_t)n_tiles;
+  if (a.Wsp != nullptr) {
+    if (a.val) hipLaunchKernelGGL((agg_dense_pc_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, true>), grid, block, 0, st, a, ctr, nt);
+    else hipLaunchKernelGGL((agg_dense_pc_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, true>), grid, block, 0, st, a, ctr, nt);
+  } else {
+    if (a.val) hipLaunchKernelGGL((agg_dense_pc_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, false>), grid, block, 0, st, a, ctr, nt);
+    else hipLaunchKernelGGL((agg_dense_pc_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, false>), grid, block, 0, st, a, ctr, nt);
+  }
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+  }
 }
 
 // out[rows[k], :] = act(out[rows[k], :] + sum_{e in [crp[k], crp[k+1])} val[e] * Z[slot[e], :]) — one wave per
