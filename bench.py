@@ -258,7 +258,8 @@ def run_aggregate(args, rank, world, dev):
             layer = {"what": "relu((A_hat X) W + b), F = d_out = %d" % d, "one_kernel_ms": t_one,
                      "two_kernel_ms": t_two, "mfma_tflops_inside_one_kernel": 2.0 * n * d * d / (t_one * 1e-3) / 1e12,
                      "max_rel_diff_first_4096_rows": err,
-                     "kernel": "mp::agg_dense_kernel (32-row tiles reduced into LDS, MFMA against W from L2)"}
+                     "kernel": "mp::agg_dense_pc_kernel (64-row tiles, 4 gathering + 4 multiplying waves per workgroup, two LDS "
+                               "buffers, bf16x3 MFMA against W from L2)"}
             del y2, y3
         except Exception as e:   # never let the side measurement take the metric down
             layer = {"error": repr(e)[:200]}

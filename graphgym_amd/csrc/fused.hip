@@ -59,8 +59,16 @@ constexpr int kTileRows = 32;
 #ifdef MP_FUSED_TIMING
 __device__ long long g_dbg[1 << 18];
 #define DBG_T(slot) do { if (dbg_on && lane == 0) g_dbg[dbg_base + wave * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+// (producer/consumer kernel: workgroups 5, 37, 69, ... stamp their first 1000 items: producer wave 0 in slots 0-3, the
+// first consumer wave in slots 4-7)
+#define PC_T(slot) do { if ((blockIdx.x & 31) == 5 && (blockIdx.x >> 5) < 8 && it < 1000 && lane == 0) \
+  g_dbg[(((blockIdx.x >> 5) * 1000 + it) << 3) + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DBG_T(slot) do {} while (0)
+#define PC_T(slot) do {} while (0)
+#endif
+#ifndef MP_W_RING
+#define MP_W_RING 2    // K groups the W fragments of the 64-row kernel are fetched ahead
 #endif
 #ifndef MP_FUSED_U
 #define MP_FUSED_U 16   // neighbour rows in flight per wave in phase A
@@ -123,6 +131,11 @@ __device__ __forceinline__ void mfma_half_bf16x3(const float (*T)[FH + 4], const
   // loads run one group ahead without a second buffer (a double buffer spills at four waves per SIMD).
   bf16x8 bq[2][3];
   auto fetch = [&](int sp, int g) {
+#if defined(MP_ABL_W_L1)      // (ablation builds: every K group reads group 0 / plane 2 re-reads plane 1)
+    g = 0;
+#elif defined(MP_ABL_W_2P)
+    if (sp == 2) { bq[0][2] = bq[0][1]; bq[1][2] = bq[1][1]; return; }
+#endif
     bq[0][sp] = *reinterpret_cast<const bf16x8*>(w0 + sp * plane + g * gstride);
     bq[1][sp] = *reinterpret_cast<const bf16x8*>(w1 + sp * plane + g * gstride);
   };
@@ -442,6 +455,187 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
   }
 }
 
+// The same two products for RB 32-row blocks of one tile at once (the producer/consumer kernel below): every W fragment
+// is fetched once and used RB times — the fragments, L2 hits, are what the product costs (see that kernel).
+template <int FH, int RB, int NB>
+__device__ __forceinline__ void mfma_rows_bf16x3(const float (*T)[FH + 4], const __bf16* __restrict__ w0,
+                                                 int64_t bstride, int64_t gstride, int64_t plane,
+                                                 f32x16 (&acc)[NB][RB][2], int fr, int kk) {
+  // NB column blocks (bstride elements apart in W) walk K together: one split of the tile's values and one fetch round
+  // trip per K group serve all of them (a wave with two blocks, one after the other, waits twice as often).
+  bf16x8 bq[NB][2][3];
+  auto fetch = [&](int sp, int g) {
+#if defined(MP_ABL_W_L1)      // (ablation builds: every K group reads group 0 / plane 2 re-reads plane 1)
+    g = 0;
+#elif defined(MP_ABL_W_2P)
+    if (sp == 2) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n) { bq[n][0][2] = bq[n][0][1]; bq[n][1][2] = bq[n][1][1]; }
+      return;
+    }
+#endif
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      bq[n][0][sp] = *reinterpret_cast<const bf16x8*>(w0 + n * bstride + sp * plane + g * gstride);
+      bq[n][1][sp] = *reinterpret_cast<const bf16x8*>(w0 + n * bstride + 8 + sp * plane + g * gstride);
+    }
+  };
+  fetch(2, 0); fetch(1, 0); fetch(0, 0);
+#pragma unroll
+  for (int g = 0; g < FH / 16; ++g) {
+    const bool more = g + 1 < FH / 16;
+    bf16x8 a0[RB], a1[RB], a2[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const f32x4 alo = *reinterpret_cast<const f32x4*>(&T[32 * b + fr][16 * g + 8 * kk]);
+      const f32x4 ahi = *reinterpret_cast<const f32x4*>(&T[32 * b + fr][16 * g + 8 * kk + 4]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x = i < 4 ? alo[i] : ahi[i - 4];
+        const __bf16 b0 = (__bf16)x;
+        const float r1 = x - (float)b0;
+        const __bf16 b1 = (__bf16)r1;
+        const float r2 = r1 - (float)b1;
+        a0[b][i] = b0; a1[b][i] = b1; a2[b][i] = (__bf16)r2;
+      }
+    }
+    // (per accumulator the order of the six terms is that of mfma_half_bf16x3: same bits for every tile height)
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        acc[n][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[n][0][2], acc[n][b][0], 0, 0, 0);
+        acc[n][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[n][1][2], acc[n][b][1], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) fetch(2, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        acc[n][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[b], bq[n][0][1], acc[n][b][0], 0, 0, 0);
+        acc[n][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[b], bq[n][1][1], acc[n][b][1], 0, 0, 0);
+        acc[n][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[n][0][1], acc[n][b][0], 0, 0, 0);
+        acc[n][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[n][1][1], acc[n][b][1], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) fetch(1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        acc[n][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[b], bq[n][0][0], acc[n][b][0], 0, 0, 0);
+        acc[n][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[b], bq[n][1][0], acc[n][b][1], 0, 0, 0);
+        acc[n][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[b], bq[n][0][0], acc[n][b][0], 0, 0, 0);
+        acc[n][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[b], bq[n][1][0], acc[n][b][1], 0, 0, 0);
+        acc[n][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[n][0][0], acc[n][b][0], 0, 0, 0);
+        acc[n][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[n][1][0], acc[n][b][1], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) fetch(0, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The same with the W fragments in a ring of D + 1 slots, fetched D whole K groups ahead: behind the gathers of the CU's
+// other waves a fragment (an L2 hit) takes ~1.5 us to arrive while a group's MFMAs take 0.3 us, and the rolling refill
+// above runs at most one group ahead.  For the instantiations with registers to spare (K in one half, one block).
+template <int FH, int RB, int D>
+__device__ __forceinline__ void mfma_rows_bf16x3_ring(const float (*T)[FH + 4], const __bf16* __restrict__ w0,
+                                                      int64_t gstride, int64_t plane, f32x16 (&acc)[1][RB][2], int fr, int kk) {
+  constexpr int G = FH / 16;
+  bf16x8 bq[D + 1][2][3];
+  auto fetch = [&](int slot, int g) {
+#if defined(MP_ABL_W_L1)
+    g = 0;
+#endif
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) {
+      bq[slot][0][sp] = *reinterpret_cast<const bf16x8*>(w0 + sp * plane + g * gstride);
+      bq[slot][1][sp] = *reinterpret_cast<const bf16x8*>(w0 + 8 + sp * plane + g * gstride);
+    }
+  };
+#pragma unroll
+  for (int g = 0; g < D && g < G; ++g) fetch(g, g);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int cur = g % (D + 1);
+    if (g + D < G) fetch((g + D) % (D + 1), g + D);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 a0[RB], a1[RB], a2[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const f32x4 alo = *reinterpret_cast<const f32x4*>(&T[32 * b + fr][16 * g + 8 * kk]);
+      const f32x4 ahi = *reinterpret_cast<const f32x4*>(&T[32 * b + fr][16 * g + 8 * kk + 4]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x = i < 4 ? alo[i] : ahi[i - 4];
+        const __bf16 b0 = (__bf16)x;
+        const float r1 = x - (float)b0;
+        const __bf16 b1 = (__bf16)r1;
+        const float r2 = r1 - (float)b1;
+        a0[b][i] = b0; a1[b][i] = b1; a2[b][i] = (__bf16)r2;
+      }
+    }
+    // (the order of the six terms per accumulator is that of mfma_half_bf16x3: same bits)
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      acc[0][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[cur][0][2], acc[0][b][0], 0, 0, 0);
+      acc[0][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[cur][1][2], acc[0][b][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      acc[0][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[b], bq[cur][0][1], acc[0][b][0], 0, 0, 0);
+      acc[0][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[b], bq[cur][1][1], acc[0][b][1], 0, 0, 0);
+      acc[0][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[cur][0][1], acc[0][b][0], 0, 0, 0);
+      acc[0][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[cur][1][1], acc[0][b][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      acc[0][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[b], bq[cur][0][0], acc[0][b][0], 0, 0, 0);
+      acc[0][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[b], bq[cur][1][0], acc[0][b][1], 0, 0, 0);
+      acc[0][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[b], bq[cur][0][0], acc[0][b][0], 0, 0, 0);
+      acc[0][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[b], bq[cur][1][0], acc[0][b][1], 0, 0, 0);
+      acc[0][b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[cur][0][0], acc[0][b][0], 0, 0, 0);
+      acc[0][b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[b], bq[cur][1][0], acc[0][b][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int FH, int PF, int RB>
+__device__ __forceinline__ void mfma_rows(const float (*T)[FH + 4], const float* __restrict__ wp, int64_t ldw,
+                                          f32x16 (&acc)[RB][2], int fr, int kk) {
+  f32x2 bq[PF + 1][4];
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bq[p][j] = *reinterpret_cast<const f32x2*>(wp + (int64_t)(8 * p + j) * ldw);
+#pragma unroll
+  for (int g = 0; g < FH / 8; ++g) {
+    const int cur = g % (PF + 1), nxt = (g + PF) % (PF + 1);
+    if (g + PF < FH / 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bq[nxt][j] = *reinterpret_cast<const f32x2*>(wp + (int64_t)(8 * (g + PF) + j) * ldw);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&T[32 * b + fr][8 * g + 4 * kk]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bq[cur][j][0], acc[b][0], 0, 0, 0);
+        acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bq[cur][j][1], acc[b][1], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The same layer with the two phases on DIFFERENT waves (round 3).  Measured on the kernel above
 // (profiles/r03_fused_phases.json): a workgroup gathers only 60 % of its time — phase B is 24 % (its W fragments are L2
@@ -457,14 +651,28 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 3 : 4) void agg_dense_kernel(Fuse
 // (profiles/r03_occupancy_sweep.jsonl).  Tiles come from an atomic counter in ascending order, so the hub tiles at the
 // head of the matrix start first and a workgroup that holds one simply draws fewer tiles; which workgroup computes a
 // tile does not enter its arithmetic: same bits as the kernel above.
-constexpr int kPcThreads = 512;
-constexpr int kPcGather = 4;      // producer waves (and consumer waves) per workgroup
-
-template <int W, bool WEIGHTED, int U, int KH, int NCB, int PF, bool NT_OUT, bool BF16X3>
-__global__ __launch_bounds__(kPcThreads, 4) void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr,
-                                                                     int32_t n_tiles) {
+//
+// TR rows per tile, NP producer waves (the consumers are always four: 64 output columns each).  Every tile reads ALL of
+// W from L2 — 6 bytes per weight in the three-way bf16 split, 393 KB at F = dout = 256, more than the tile's own
+// gathers (352 KB) — and that traffic is what the product costs: with W served from L1 the layer runs at 20.0 ms,
+// below the plain aggregation (in-process ablations, profiles/r03_fused_ablation.json: 22.3 ms as is, 21.2 ms with one of
+// the three planes not read, 19.7 ms without the product, 17.6 ms without product and store).  A tile of TR = 64 rows
+// uses every W fragment for two 32-row MFMA blocks: half the traffic.  Its two buffers take 133 KB of LDS — one
+// workgroup per CU — so the workgroup brings its own 8 gathering waves (NP = 8: 12 waves, 168 registers each).
+// NC consumer waves, 64 output columns each: 4 for dout <= 256; 8 for wider outputs, where four consumers — two column
+// blocks each, a W fragment round trip of ~1 us per K group and block behind the CU's gathers — take longer than the
+// producers need for the next tile and the layer becomes consumer-bound (F = dout = 512: 53.2 ms with 4, XX with 8).
+template <int W, bool WEIGHTED, int U, int KH, int NCB, int PF, bool NT_OUT, bool BF16X3, int TR, int NP, int NC>
+__global__ __launch_bounds__((NP + NC) * kWave, TR == 64 ? (NP + NC + 3) / 4 : 4)
+void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32_t n_tiles) {
   constexpr int FH = kWave * W;
   constexpr int LDT = FH + 4;
+  constexpr int kPcGather = NP;
+  constexpr int kTileRows = TR;
+  constexpr int kPcThreads = (NP + NC) * kWave;
+  constexpr int kPcCons = NC;
+  constexpr int RB = TR / 32;       // 32-row MFMA blocks per tile
+  static_assert(TR == 32 || TR == 64, "a tile's row starts live in one wave");
   __shared__ __attribute__((aligned(16))) float T[2][kTileRows][LDT];
   __shared__ __attribute__((aligned(16))) float carry[kPcGather - 1][FH];
   __shared__ int carry_row[kPcGather];
@@ -494,122 +702,162 @@ __global__ __launch_bounds__(kPcThreads, 4) void agg_dense_pc_kernel(FusedArgs a
   int buf = 0;
   const bool has_s = a.S != nullptr;          // the self term initialises the tile (GIN's (1 + eps) x): one more barrier
 
-  // producer state of the current tile (the same for every K half)
-  int rp_v = INT_MAX, rp_nxt = INT_MAX, es = 0, ee = 0, first_rl = -1;
-  bool cont = false;
-  if (producer && cur_tile >= 0)
-    rp_nxt = lane <= kTileRows ? a.rowptr[min(cur_tile * kTileRows + lane, min(cur_tile * kTileRows + kTileRows, a.N))] : INT_MAX;
-  // consumer accumulators (KH == 2: live across the two halves of a tile)
-  f32x16 acc[KH == 2 ? NCB : 1][2];
-
-  while (cur_tile >= 0 || prev_tile >= 0) {
-    const int R0 = cur_tile * kTileRows;
-    const int R1 = min(R0 + kTileRows, a.N);
-    const int k0 = cur_kh * FH;
-    // ================= producers: set up (cur_tile, cur_kh) in buffer `buf` =================
-    if (producer && cur_tile >= 0) {
-      if (cur_kh == 0) {
-        rp_v = rp_nxt;                         // requested one item ago: the load does not wait behind this CU's gathers
-        if (wave == 0) {
-          const int nxt = __shfl_down(rp_v, 1, kWave);
-          if (lane < kTileRows) {
-            inv_deg[buf][lane] = (a.mean && nxt > rp_v) ? 1.0f / (float)(nxt - rp_v) : (a.mean ? 0.f : 1.f);
-            defer_l[buf][lane] = (a.defer_act != nullptr && R0 + lane < R1) ? (int)a.defer_act[R0 + lane] : 0;
-          }
-        }
-        const int E0 = bcast_i(rp_v, 0);
-        const int E1 = bcast_i(rp_v, kTileRows);
-        const int q = (E1 - E0 + kPcGather - 1) / kPcGather;
-        es = min(E0 + wave * q, E1);
-        ee = min(es + q, E1);
-        first_rl = -1;
-        cont = false;
-        if (es < ee) {
-          const unsigned long long started = __ballot(lane >= 1 && lane <= kTileRows && rp_v <= es);
-          first_rl = __builtin_amdgcn_readfirstlane((int)__popcll(started));
-          cont = bcast_i(rp_v, first_rl) < es;
-        }
-      } else if (wave == 0 && lane < kTileRows) {      // second half: the tile's scales move to this buffer
-        inv_deg[buf][lane] = inv_deg[buf ^ 1][lane];
-        defer_l[buf][lane] = defer_l[buf ^ 1][lane];
+  // The two roles run SEPARATE loops over the same item sequence (the workgroup barriers b0 / b1 / b2 pair up by
+  // count: s_barrier counts arriving waves, wherever they are in the code), so the registers of the gathers in
+  // flight and of the MFMA accumulators are never live in the same code.
+  if (producer) {
+    // producer state: the run of the item being gathered (rp_v: the tile's 33 row starts, lane i = row i; [es, ee): this
+    // wave's entries; cvF / wvF: its first 64 indices / values; vb: its first U rows, requested BEFORE the barriers that
+    // close the previous item when `pre` is set) and the same for the next item (suffix 1), prepared while this one runs
+    typedef const int __attribute__((address_space(4))) cint_t;
+    cint_t* __restrict__ rps = (cint_t*)(uintptr_t)a.rowptr;
+    int rp_v = INT_MAX, rp_e = 0, es = 0, ee = 0, first_rl = -1, cvF = 0;   // (rp_e: the tile's last row start + its count)
+    float wvF = 1.f;
+    bool cont = false, pre = false;
+    int rp1 = INT_MAX, rp_e1 = 0, es1 = 0, ee1 = 0, first_rl1 = -1, cv1 = 0;
+    float wv1 = 1.f;
+    bool cont1 = false;
+    float vb[U][W];
+    // row starts of a tile through the scalar cache (a uniform address; not queued behind the CU's gathers)
+    // (lane i = start of tile row i, i < TR; `end` = start of row TR = the end of the tile's entries; rows past the end
+    // of the matrix are empty)
+    auto row_starts = [&](int tile, int& end) {
+      const int NR0 = tile * kTileRows;
+      int r = INT_MAX;
+      if (NR0 + kTileRows <= a.N) {
+#pragma unroll
+        for (int i = 0; i < kTileRows; ++i) { const int vi = rps[NR0 + i]; r = lane == i ? vi : r; }
+        end = rps[NR0 + kTileRows];
+      } else {
+        const int NR1 = a.N;
+#pragma unroll
+        for (int i = 0; i < kTileRows; ++i) { const int vi = rps[min(NR0 + i, NR1)]; r = lane == i ? vi : r; }
+        end = rps[NR1];
       }
-      if (lane == 0) carry_row[wave] = cont ? first_rl : -1;
-      if (has_s) {
-        constexpr int VPR = FH / 4;
-        for (int i = tid; i < kTileRows * VPR; i += kPcGather * kWave) {
-          const int m = i / VPR, c = (i % VPR) * 4;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (R0 + m < R1) {
-            v = *reinterpret_cast<const f32x4*>(a.S + (int64_t)(R0 + m) * a.lds + k0 + c);
-            v *= a.self_scale;
-          }
-          *reinterpret_cast<f32x4*>(&T[buf][m][c]) = v;
-        }
+      return r;
+    };
+    auto rp_at = [&](int rp, int end, int r) { return r >= kTileRows ? end : bcast_i(rp, r); };   // r: wave-uniform
+    // this wave's quarter of a tile's entries: [s, e), the tile row its first entry lies in, and whether that row began
+    // in an earlier wave's run
+    auto run_of = [&](int rp, int E1, int& s_, int& e_, int& frl, bool& ct) {
+      const int E0 = bcast_i(rp, 0);
+      const int q = (E1 - E0 + kPcGather - 1) / kPcGather;
+      s_ = min(E0 + wave * q, E1);
+      e_ = min(s_ + q, E1);
+      frl = -1;
+      ct = false;
+      if (s_ < e_) {
+        const unsigned long long started = __ballot(lane >= 1 && lane < kTileRows && rp <= s_);   // (row TR starts at E1 > s_)
+        frl = __builtin_amdgcn_readfirstlane((int)__popcll(started));
+        ct = bcast_i(rp, frl) < s_;
+      }
+    };
+    if (cur_tile >= 0) {
+      rp_v = row_starts(cur_tile, rp_e);
+      run_of(rp_v, rp_e, es, ee, first_rl, cont);
+      if (es < ee) {
+        cvF = a.col[min(es + lane, ee - 1)];
+        if (WEIGHTED) wvF = a.val[min(es + lane, ee - 1)];
       }
     }
-    if (producer && nxt_tile >= 0 && nxt_kh == 0) {   // the next tile's row starts, one item ahead
-      const int NR0 = nxt_tile * kTileRows;
-      rp_nxt = lane <= kTileRows ? a.rowptr[min(NR0 + lane, min(NR0 + kTileRows, a.N))] : INT_MAX;
-    }
-    if (has_s) __syncthreads();   // b0 (self term only): buffer `buf` initialised before the runs add into it
-
-    if (producer) {
-      // ================= producers: phase A of (cur_tile, cur_kh) =================
-      if (cur_tile >= 0 && !has_s && wave == 0 && bcast_i(rp_v, 0) == bcast_i(rp_v, kTileRows)) {
-        float z[W];                                      // a tile without a single entry
-#pragma unroll
-        for (int k = 0; k < W; ++k) z[k] = 0.f;
-        for (int r = 0; r < kTileRows; ++r) store_vec<W>(&T[buf][r][lane * W], z);
+    int it = 0;
+    while (cur_tile >= 0 || prev_tile >= 0) {
+      if (wave == 0) PC_T(0);
+      const int R0 = cur_tile * kTileRows;
+      const int R1 = min(R0 + kTileRows, a.N);
+      const int k0 = cur_kh * FH;
+      // ================= producers: set up (cur_tile, cur_kh) in buffer `buf` =================
+      if (cur_tile >= 0) {
+        if (cur_kh == 0) {
+          if (wave == 0) {
+            int nxt = __shfl_down(rp_v, 1, kWave);
+            if (lane == kTileRows - 1) nxt = rp_e;
+            if (lane < kTileRows) {
+              inv_deg[buf][lane] = (a.mean && nxt > rp_v) ? 1.0f / (float)(nxt - rp_v) : (a.mean ? 0.f : 1.f);
+              defer_l[buf][lane] = (a.defer_act != nullptr && R0 + lane < R1) ? (int)a.defer_act[R0 + lane] : 0;
+            }
+          }
+        } else if (wave == 0 && lane < kTileRows) {      // second half: the tile's scales move to this buffer
+          inv_deg[buf][lane] = inv_deg[buf ^ 1][lane];
+          defer_l[buf][lane] = defer_l[buf ^ 1][lane];
+        }
+        if (lane == 0) carry_row[wave] = cont ? first_rl : -1;
+        if (has_s) {
+          constexpr int VPR = FH / 4;
+          for (int i = tid; i < kTileRows * VPR; i += kPcGather * kWave) {
+            const int m = i / VPR, c = (i % VPR) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (R0 + m < R1) {
+              v = *reinterpret_cast<const f32x4*>(a.S + (int64_t)(R0 + m) * a.lds + k0 + c);
+              v *= a.self_scale;
+            }
+            *reinterpret_cast<f32x4*>(&T[buf][m][c]) = v;
+          }
+        }
       }
-      if (cur_tile >= 0 && es < ee) {
-        const float* __restrict__ xlane = a.X + k0 + lane * W;
-        int rl = first_rl;
-        int rend = bcast_i(rp_v, rl + 1);
-        float accr[W];
-#pragma unroll
-        for (int k = 0; k < W; ++k) accr[k] = 0.f;
-        // Without a self term nothing initialises the tile: the wave in whose run a row STARTS stores the row (also a
-        // row without entries it passes over), later parts of a cut row go to the carries, and the rows no run passes
-        // over — empty rows in front of a run's first entry, and behind the tile's last entry — are zeroed by that run.
-        auto flush = [&]() {
-          if (cont && rl == first_rl) {
-            store_vec<W>(&carry[wave - 1][lane * W], accr);
-          } else if (has_s) {
-            float t[W];
-            load_vec<W>(&T[buf][rl][lane * W], t);
-#pragma unroll
-            for (int k = 0; k < W; ++k) t[k] += accr[k];
-            store_vec<W>(&T[buf][rl][lane * W], t);
-          } else {
-            store_vec<W>(&T[buf][rl][lane * W], accr);
-          }
-#pragma unroll
-          for (int k = 0; k < W; ++k) accr[k] = 0.f;
-        };
-        if (!has_s) {   // the empty rows between the previous run's last entry (or the tile's head) and this run's first
-          int lo = 0;
-          if (es > bcast_i(rp_v, 0)) {
-            const unsigned long long before = __ballot(lane >= 1 && lane <= kTileRows && rp_v <= es - 1);
-            lo = __builtin_amdgcn_readfirstlane((int)__popcll(before)) + 1;
-          }
-          float z[W];
+      if (nxt_tile >= 0) {   // the next item's run and its first index batch: on their way while this item runs
+        if (nxt_kh == 0) {
+          rp1 = row_starts(nxt_tile, rp_e1);
+          run_of(rp1, rp_e1, es1, ee1, first_rl1, cont1);
+        } else {
+          rp1 = rp_v; rp_e1 = rp_e; es1 = es; ee1 = ee; first_rl1 = first_rl; cont1 = cont;
+        }
+        if (es1 < ee1) {
+          cv1 = a.col[min(es1 + lane, ee1 - 1)];
+          if (WEIGHTED) wv1 = a.val[min(es1 + lane, ee1 - 1)];
+        }
+      }
+      if (has_s) __syncthreads();   // b0 (self term only): buffer `buf` initialised before the runs add into it
+
+      {
+        // ================= producers: phase A of (cur_tile, cur_kh) =================
+        if (cur_tile >= 0 && !has_s && wave == 0 && bcast_i(rp_v, 0) == rp_e) {
+          float z[W];                                      // a tile without a single entry
 #pragma unroll
           for (int k = 0; k < W; ++k) z[k] = 0.f;
-          for (int r = lo; r < first_rl; ++r) store_vec<W>(&T[buf][r][lane * W], z);
+          for (int r = 0; r < kTileRows; ++r) store_vec<W>(&T[buf][r][lane * W], z);
         }
-        for (int ec = es; ec < ee; ec += kWave) {
-          const int me = min(ec + lane, ee - 1);
-          const int cv = a.col[me] & 0x7fffffff;   // an identity mark (sign bit) is not part of the index
-          float wv = 1.f;
-          if (WEIGHTED) wv = a.val[me];
-          const int n = min(kWave, ee - ec);
-          for (int jb = 0; jb < n; jb += U) {
-            float v[U][W];
+        if (cur_tile >= 0 && es < ee) {
+          const float* __restrict__ xlane = a.X + k0 + lane * W;
+          int rl = first_rl;
+          int rend = rp_at(rp_v, rp_e, rl + 1);
+          float accr[W];
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-              const int c = bcast_i(cv, jb + j);
-              load_vec<W>(xlane + (int64_t)c * a.ldx, v[j]);
+          for (int k = 0; k < W; ++k) accr[k] = 0.f;
+          // Without a self term nothing initialises the tile: the wave in whose run a row STARTS stores the row (also a
+          // row without entries it passes over), later parts of a cut row go to the carries, and the rows no run passes
+          // over — empty rows in front of a run's first entry, and behind the tile's last entry — are zeroed by that run.
+          auto flush = [&]() {
+            if (cont && rl == first_rl) {
+              store_vec<W>(&carry[wave - 1][lane * W], accr);
+            } else if (has_s) {
+              float t[W];
+              load_vec<W>(&T[buf][rl][lane * W], t);
+#pragma unroll
+              for (int k = 0; k < W; ++k) t[k] += accr[k];
+              store_vec<W>(&T[buf][rl][lane * W], t);
+            } else {
+              store_vec<W>(&T[buf][rl][lane * W], accr);
             }
+#pragma unroll
+            for (int k = 0; k < W; ++k) accr[k] = 0.f;
+          };
+          if (!has_s) {   // the empty rows between the previous run's last entry (or the tile's head) and this run's first
+            int lo = 0;
+            if (es > bcast_i(rp_v, 0)) {
+              const unsigned long long before = __ballot(lane >= 1 && lane < kTileRows && rp_v <= es - 1);
+              lo = __builtin_amdgcn_readfirstlane((int)__popcll(before)) + 1;
+            }
+            float z[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) z[k] = 0.f;
+            for (int r = lo; r < first_rl; ++r) store_vec<W>(&T[buf][r][lane * W], z);
+          }
+          auto issue_burst = [&](int cvb, int jb, const float* __restrict__ xl) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) load_vec<W>(xl + (int64_t)bcast_i(cvb, jb + j) * a.ldx, vb[j]);
+          };
+          auto consume_burst = [&](int ec, int jb, float wvb) {
 #pragma unroll
             for (int j = 0; j < U; ++j) {
               const int e = ec + jb + j;
@@ -617,33 +865,95 @@ __global__ __launch_bounds__(kPcThreads, 4) void agg_dense_pc_kernel(FusedArgs a
                 while (e >= rend) {
                   flush();
                   rl += 1;
-                  rend = bcast_i(rp_v, rl + 1);
+                  rend = rp_at(rp_v, rp_e, rl + 1);
                 }
-                const float w = WEIGHTED ? bcast_f(wv, jb + j) : 1.f;
+                const float w = WEIGHTED ? bcast_f(wvb, jb + j) : 1.f;
 #pragma unroll
-                for (int k = 0; k < W; ++k) accr[k] = fmaf(w, v[j][k], accr[k]);
+                for (int k = 0; k < W; ++k) accr[k] = fmaf(w, vb[j][k], accr[k]);
               }
             }
+          };
+          int cvb = cvF & 0x7fffffff;   // an identity mark (sign bit) is not part of the index
+          float wvb = wvF;
+          int jb0 = 0;
+          if (pre) {   // the first U rows were requested before the barriers that closed the previous item
+            consume_burst(es, 0, wvb);
+            jb0 = U;
+          }
+          for (int ec = es; ec < ee; ec += kWave, jb0 = 0) {
+            if (ec != es) {
+              const int me = min(ec + lane, ee - 1);
+              cvb = a.col[me] & 0x7fffffff;
+              if (WEIGHTED) wvb = a.val[me];
+            }
+            const int n = min(kWave, ee - ec);
+            for (int jb = jb0; jb < n; jb += U) {
+              issue_burst(cvb, jb, xlane);
+              consume_burst(ec, jb, wvb);
+            }
+          }
+          flush();
+          if (!has_s && ee == rp_e) {   // this run closes the tile: the empty rows behind it
+            float z[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) z[k] = 0.f;
+            for (int r = rl + 1; r < kTileRows; ++r) store_vec<W>(&T[buf][r][lane * W], z);
           }
         }
-        flush();
-        if (!has_s && ee == bcast_i(rp_v, kTileRows)) {   // this run closes the tile: the empty rows behind it
-          float z[W];
+        pre = false;
+        if (nxt_tile >= 0 && es1 < ee1) {   // the next item's first U rows travel through the barriers below
+          const float* __restrict__ xl1 = a.X + nxt_kh * FH + lane * W;
+          const int c1 = cv1 & 0x7fffffff;
 #pragma unroll
-          for (int k = 0; k < W; ++k) z[k] = 0.f;
-          for (int r = rl + 1; r < kTileRows; ++r) store_vec<W>(&T[buf][r][lane * W], z);
+          for (int j = 0; j < U; ++j) load_vec<W>(xl1 + (int64_t)bcast_i(c1, j) * a.ldx, vb[j]);
+          pre = true;
         }
       }
-    } else if (prev_tile >= 0) {
-      // ================= consumers: (prev_tile, prev_kh) from buffer buf ^ 1 =================
+      if (wave == 0) PC_T(1);
+      __syncthreads();   // b1: every producer run is reduced into `buf` (and the consumers are done with buf ^ 1)
+      if (wave == 0) PC_T(2);
+
+      // ---- carries: a row cut by run boundaries gets its later parts in wave order ----
+      if (cur_tile >= 0 && tid < FH) {
+#pragma unroll
+        for (int w = 1; w < kPcGather; ++w) {
+          const int cr = carry_row[w];
+          if (cr >= 0) T[buf][cr][tid] += carry[w - 1][tid];
+        }
+      }
+      __syncthreads();   // b2: buffer `buf` complete; next_tile_s published by the consumers
+      if (wave == 0) PC_T(3);
+      ++it;
+
+      rp_v = rp1; rp_e = rp_e1; es = es1; ee = ee1; first_rl = first_rl1; cont = cont1; cvF = cv1; wvF = wv1;
+      prev_tile = cur_tile; prev_kh = cur_kh;
+      cur_tile = nxt_tile; cur_kh = nxt_kh;
+      if (nxt_tile >= 0) {
+        if (nxt_kh + 1 < KH) {
+          nxt_kh += 1;
+        } else {
+          nxt_kh = 0;
+          nxt_tile = next_tile_s < n_tiles ? next_tile_s : -1;
+        }
+      }
+      buf ^= 1;
+    }
+  } else {
+    // consumer accumulators (KH == 2: live across the two halves of a tile)
+    f32x16 acc[KH == 2 ? NCB : 1][RB][2];
+    int it = 0;   // (items seen; used by the timing build only)
+
+    // one item of consumer work: (prev_tile, K half PKH) from buffer buf ^ 1.  (Walking the two halves of a tile in
+    // straight-line code, the half a compile-time constant, was tried: the allocator does worse, 1.3-3.8 KB of scratch.)
+    auto work = [&](const int PKH) {
       const int pb = buf ^ 1;
       const int PR0 = prev_tile * kTileRows;
       const int PR1 = min(PR0 + kTileRows, a.N);
-      const int pk0 = prev_kh * FH;
+      const int pk0 = PKH * FH;
       const int ctid = tid - kPcGather * kWave;
       if (a.P != nullptr) {   // the aggregated rows, kept for the weight gradient
         constexpr int VPR = FH / 4;
-        for (int i = ctid; i < kTileRows * VPR; i += kPcGather * kWave) {
+        for (int i = ctid; i < kTileRows * VPR; i += kPcCons * kWave) {
           const int m = i / VPR, c = (i % VPR) * 4;
           if (PR0 + m < PR1) {
             f32x4 v = *reinterpret_cast<const f32x4*>(&T[pb][m][c]);
@@ -652,7 +962,7 @@ __global__ __launch_bounds__(kPcThreads, 4) void agg_dense_pc_kernel(FusedArgs a
           }
         }
       }
-      auto store_block = [&](const f32x16& acc0, const f32x16& acc1, int n0) {
+      auto store_block = [&](const f32x16& acc0, const f32x16& acc1, int n0, int rb) {   // rows [32 rb, 32 rb + 32) of the tile
         int fr = fr_c, kk = kk_c;   // (re-derived behind the accumulators: see the kernel above)
         asm volatile("" : "+v"(fr), "+v"(kk) : "v"(acc0[0]), "v"(acc1[15]));
         const int cpair = n0 + 2 * fr;
@@ -674,7 +984,7 @@ __global__ __launch_bounds__(kPcThreads, 4) void agg_dense_pc_kernel(FusedArgs a
           const int c4 = n0 + 2 * (fr & ~1);
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * kk;       // rows rl, rl + 1
+            const int rl = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kk;       // rows rl, rl + 1
             const f32x2 m0 = finish(r, rl), m1 = finish(r + 1, rl + 1);
             const f32x2 send = odd ? m0 : m1;
             f32x2 recv;
@@ -695,7 +1005,7 @@ __global__ __launch_bounds__(kPcThreads, 4) void agg_dense_pc_kernel(FusedArgs a
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int rl = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kk;
             const int row = PR0 + rl;
             const f32x2 o = finish(r, rl);
             if (col_ok && row < PR1) *reinterpret_cast<f32x2*>(a.out + (int64_t)row * a.ldo + cpair) = o;
@@ -703,80 +1013,133 @@ __global__ __launch_bounds__(kPcThreads, 4) void agg_dense_pc_kernel(FusedArgs a
         }
       };
       if constexpr (KH == 1) {
-        for (int cb = 0; cb < a.dout; cb += 64 * kPcGather) {
+        for (int cb = 0; cb < a.dout; cb += 64 * kPcCons) {
           const int n0 = cb + cw * 64;
           if (n0 >= a.dout) break;                       // wave-uniform
           const int cpair = n0 + 2 * fr;
           const int ccol = cpair < a.dout ? cpair : a.dout - 2;
-          f32x16 acc0, acc1;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+          for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0][b][0][r] = 0.f; acc[0][b][1][r] = 0.f; }
+#ifndef MP_PC_NO_MFMA
           if constexpr (BF16X3) {
             const __bf16* w0 = a.Wsp + ((int64_t)kk * a.dout + ccol) * 8;
-            mfma_half_bf16x3<FH>(T[pb], w0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, acc0, acc1, fr, kk);
+            // (64-row tiles, 4 consumers: 169 of 256 registers — room for fragments two K groups ahead: 21.09 -> 20.93 ms,
+            // aggregated rows kept 23.03 -> 22.65 ms; three ahead: the same)
+            if constexpr (TR == 64 && NC == 4) mfma_rows_bf16x3_ring<FH, RB, MP_W_RING>(T[pb], w0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, acc, fr, kk);
+            else mfma_rows_bf16x3<FH, RB, 1>(T[pb], w0, 0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, acc, fr, kk);
           } else {
             const float* __restrict__ wp = a.Wm + (int64_t)(4 * kk) * a.ldw + ccol;
-            mfma_half<FH, PF>(T[pb], wp, a.ldw, acc0, acc1, fr, kk);
+            mfma_rows<FH, PF, RB>(T[pb], wp, a.ldw, acc[0], fr, kk);
           }
-          store_block(acc0, acc1, n0);
+#else
+          acc[0][0][0][0] = T[pb][fr][kk + n0];   // (ablation build: no transform)
+#endif
+#pragma unroll
+          for (int b = 0; b < RB; ++b) {
+#ifndef MP_PC_NO_STORE
+            store_block(acc[0][b][0], acc[0][b][1], n0, b);
+#else
+            if (acc[0][b][0][0] == 1.2345e-30f) store_block(acc[0][b][0], acc[0][b][1], n0, b);   // (ablation build: no output)
+#endif
+          }
         }
       } else {
-        if (prev_kh == 0) {
+        if (PKH == 0) {
 #pragma unroll
           for (int b = 0; b < NCB; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[b][0][r] = 0.f; acc[b][1][r] = 0.f; }
-        }
+            for (int q = 0; q < RB; ++q)
 #pragma unroll
-        for (int b = 0; b < NCB; ++b) {
-          const int n0 = b * 64 * kPcGather + cw * 64;
-          if (n0 < a.dout) {                             // wave-uniform
-            const int cpair = n0 + 2 * fr;
-            const int ccol = cpair < a.dout ? cpair : a.dout - 2;
-            if constexpr (BF16X3) {
-              const __bf16* w0 = a.Wsp + ((int64_t)(pk0 / 8 + kk) * a.dout + ccol) * 8;
-              mfma_half_bf16x3<FH>(T[pb], w0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, acc[b][0], acc[b][1], fr, kk);
-            } else {
-              const float* __restrict__ wp = a.Wm + (int64_t)(pk0 + 4 * kk) * a.ldw + ccol;
-              mfma_half<FH, PF>(T[pb], wp, a.ldw, acc[b][0], acc[b][1], fr, kk);
+              for (int r = 0; r < 16; ++r) { acc[b][q][0][r] = 0.f; acc[b][q][1][r] = 0.f; }
+        }
+#ifdef MP_PC_NO_MFMA
+        if (false) {
+#else
+        if constexpr (BF16X3 && NCB > 1) {
+#endif
+          // the wave's column blocks walk K together (the host sends only dout = 64 NC NCB here: every block of every
+          // wave is inside dout; a per-block path beside this one costs the allocator 146 registers of scratch)
+          const int ccol = cw * 64 + 2 * fr;
+          const __bf16* w0 = a.Wsp + ((int64_t)(pk0 / 8 + kk) * a.dout + ccol) * 8;
+          mfma_rows_bf16x3<FH, RB, NCB>(T[pb], w0, (int64_t)64 * kPcCons * 8, (int64_t)a.dout * 16,
+                                        (int64_t)a.dout * a.ldws, acc, fr, kk);
+#ifdef MP_PC_NO_MFMA
+        } else if (a.N < 0) {
+#else
+        } else {
+#endif
+#pragma unroll
+          for (int b = 0; b < NCB; ++b) {
+            const int n0 = b * 64 * kPcCons + cw * 64;
+            if (n0 < a.dout) {                             // wave-uniform
+              const int cpair = n0 + 2 * fr;
+              const int ccol = cpair < a.dout ? cpair : a.dout - 2;
+              if constexpr (BF16X3) {
+                const __bf16* w0 = a.Wsp + ((int64_t)(pk0 / 8 + kk) * a.dout + ccol) * 8;
+                f32x16 one[1][RB][2];   // (a copy in registers: a cast of acc[b] would put all of acc in scratch)
+#pragma unroll
+                for (int q = 0; q < RB; ++q) { one[0][q][0] = acc[b][q][0]; one[0][q][1] = acc[b][q][1]; }
+                mfma_rows_bf16x3<FH, RB, 1>(T[pb], w0, 0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, one, fr, kk);
+#pragma unroll
+                for (int q = 0; q < RB; ++q) { acc[b][q][0] = one[0][q][0]; acc[b][q][1] = one[0][q][1]; }
+              } else {
+                const float* __restrict__ wp = a.Wm + (int64_t)(pk0 + 4 * kk) * a.ldw + ccol;
+                mfma_rows<FH, PF, RB>(T[pb], wp, a.ldw, acc[b], fr, kk);
+              }
             }
           }
         }
-        if (prev_kh == KH - 1) {
+        if (cw == 0) PC_T(5);
+        if (PKH == KH - 1) {
 #pragma unroll
           for (int b = 0; b < NCB; ++b) {
-            const int n0 = b * 64 * kPcGather + cw * 64;
-            if (n0 < a.dout) store_block(acc[b][0], acc[b][1], n0);
+            const int n0 = b * 64 * kPcCons + cw * 64;
+            if (n0 < a.dout) {
+#pragma unroll
+              for (int q = 0; q < RB; ++q) {
+#ifdef MP_PC_NO_STORE
+                if (acc[b][q][0][0] == 1.2345e-30f)
+#endif
+                store_block(acc[b][q][0], acc[b][q][1], n0, q);
+              }
+            }
           }
         }
       }
-    }
-    __syncthreads();   // b1: every producer run is reduced into `buf` (and the consumers are done with buf ^ 1)
-
-    // ---- carries: a row cut by run boundaries gets its later parts in wave order ----
-    if (producer && cur_tile >= 0 && tid < FH) {
-#pragma unroll
-      for (int w = 1; w < kPcGather; ++w) {
-        const int cr = carry_row[w];
-        if (cr >= 0) T[buf][cr][tid] += carry[w - 1][tid];
+    };
+    auto sync_advance = [&]() {
+      if (cw == 0) PC_T(6);
+      __syncthreads();   // b1: the consumers are done with buf ^ 1
+      if (cw == 0) PC_T(7);
+      // the item after `nxt` opens a new tile when `nxt` is a last half: it is drawn here and published by b2
+      const bool draw = nxt_tile >= 0 && nxt_kh == KH - 1;
+      if (tid == kPcThreads - 1 && draw) next_tile_s = (int)atomicAdd(tile_ctr, 1u);
+      __syncthreads();   // b2
+      prev_tile = cur_tile; prev_kh = cur_kh;
+      cur_tile = nxt_tile; cur_kh = nxt_kh;
+      if (nxt_tile >= 0) {
+        if (nxt_kh + 1 < KH) {
+          nxt_kh += 1;
+        } else {
+          nxt_kh = 0;
+          nxt_tile = next_tile_s < n_tiles ? next_tile_s : -1;
+        }
+      }
+      buf ^= 1;
+      ++it;
+    };
+    if (cur_tile >= 0) {
+      if (has_s) __syncthreads();   // b0 of the first item: nothing to consume yet
+      sync_advance();
+      while (prev_tile >= 0) {      // (the producers run the same number of items)
+        if (has_s) __syncthreads();
+        if (cw == 0) PC_T(4);
+        work(prev_kh);
+        sync_advance();
       }
     }
-    // the item after `nxt` opens a new tile when `nxt` is a last half: it is drawn here and published by b2
-    const bool draw = nxt_tile >= 0 && nxt_kh == KH - 1;
-    if (tid == kPcThreads - 1 && draw) next_tile_s = (int)atomicAdd(tile_ctr, 1u);
-    __syncthreads();   // b2: buffer `buf` complete; next_tile_s published
-
-    prev_tile = cur_tile; prev_kh = cur_kh;
-    cur_tile = nxt_tile; cur_kh = nxt_kh;
-    if (nxt_tile >= 0) {
-      if (nxt_kh + 1 < KH) {
-        nxt_kh += 1;
-      } else {
-        nxt_kh = 0;
-        nxt_tile = next_tile_s < n_tiles ? next_tile_s : -1;
-      }
-    }
-    buf ^= 1;
   }
 }
 
@@ -819,31 +1182,60 @@ static int pc_counter(unsigned int** ctr, hipStream_t st) {
   return MP_OK;
 }
 
-template <int W, int KH, int NCB, int PF>
-static int launch_fused(const FusedArgs& a, hipStream_t st) {
-#ifdef MP_FUSED_TILES   // (A/B builds: the round-2 kernel)
-  return launch_fused_tiles<W, KH, NCB, PF>(a, st);
-#endif
-  // F = 512 stays on the one-role kernel: the consumer of the two-role kernel would need the accumulators of two
-  // column blocks (64 registers) beside its W fragments inside 128 registers and spills (81 ms against 57.8 ms)
-  if constexpr (KH == 2) {
-    return launch_fused_tiles<W, KH, NCB, PF>(a, st);
-  } else {
-  const int64_t n_tiles = ceil_div(a.N, kTileRows);
+template <int W, int KH, int NCB, int PF, int TR, int NP, int NC>
+static int launch_fused_pc(const FusedArgs& a, hipStream_t st) {
+  const int64_t n_tiles = ceil_div(a.N, TR);
   unsigned int* ctr = nullptr;
   const int rc = pc_counter(&ctr, st);
   if (rc != MP_OK) return rc;
-  const dim3 grid((unsigned)(n_tiles < 2 * kNumCU ? n_tiles : 2 * kNumCU)), block(kPcThreads);
+  const int64_t resident = (TR == 64 ? 1 : 2) * kNumCU;   // workgroups the chip holds at once (LDS: 133 KB / 67 KB each)
+  const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident)), block((NP + NC) * kWave);
   const int32_t nt = (int32_t)n_tiles;
   if (a.Wsp != nullptr) {
-    if (a.val) hipLaunchKernelGGL((agg_dense_pc_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, true>), grid, block, 0, st, a, ctr, nt);
-    else hipLaunchKernelGGL((agg_dense_pc_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, true>), grid, block, 0, st, a, ctr, nt);
+    if (a.val) hipLaunchKernelGGL((agg_dense_pc_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, true, TR, NP, NC>), grid, block, 0, st, a, ctr, nt);
+    else hipLaunchKernelGGL((agg_dense_pc_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, true, TR, NP, NC>), grid, block, 0, st, a, ctr, nt);
   } else {
-    if (a.val) hipLaunchKernelGGL((agg_dense_pc_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, false>), grid, block, 0, st, a, ctr, nt);
-    else hipLaunchKernelGGL((agg_dense_pc_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, false>), grid, block, 0, st, a, ctr, nt);
+    if (a.val) hipLaunchKernelGGL((agg_dense_pc_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, false, TR, NP, NC>), grid, block, 0, st, a, ctr, nt);
+    else hipLaunchKernelGGL((agg_dense_pc_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, false, TR, NP, NC>), grid, block, 0, st, a, ctr, nt);
   }
   MP_LAUNCH_CHECK();
   return MP_OK;
+}
+
+static int fused_variant() {   // MP_FUSED_VARIANT (studies: scripts/dbg/fused_variants.py), read per launch
+  const char* e = getenv("MP_FUSED_VARIANT");
+  return e ? atoi(e) : 0;
+}
+
+// Dispatch.  F >= 256: tiles of 64 rows, 4 gathering + 4 multiplying waves, one workgroup per CU.  In-process A/B at
+// 10^7 rows, 1.1 x 10^8 entries (profiles/r03_fused_variants.json), out only / aggregated rows kept:
+//   F = 256: one-role kernel 23.7 / 24.6 ms, 32 rows x 4 producers 22.5 / 24.3, 64 x 2 24.6 / 25.9, 64 x 4 20.97 / 22.98,
+//            64 x 6 21.8 / 23.9, 64 x 8 22.0 / 24.6 (plain aggregation alone: 20.7);   F = 512: 57.4 / 56.3 (32 x 4) / 53.2.
+// Narrower layers keep 32-row tiles: their buffers are small enough for two workgroups per CU either way.
+template <int W, int KH, int NCB, int PF>
+static int launch_fused(const FusedArgs& a, hipStream_t st) {
+  const int v = fused_variant();
+  if (v == 9) return launch_fused_tiles<W, KH, NCB, PF>(a, st);
+  if constexpr (W == 4) {
+    if (v == 1) return launch_fused_pc<W, KH, NCB, PF, 32, 4, 4>(a, st);
+    if constexpr (KH == 1) {
+      if (v == 2) return launch_fused_pc<W, KH, NCB, PF, 64, 8, 4>(a, st);
+      if (v == 4) return launch_fused_pc<W, KH, NCB, PF, 64, 2, 4>(a, st);
+      if (v == 5) return launch_fused_pc<W, KH, NCB, PF, 64, 6, 4>(a, st);
+    }
+    if (v == 3) return launch_fused_pc<W, KH, NCB, PF, 64, 4, 4>(a, st);
+    if constexpr (KH == 1) {
+      if (a.dout > 256) return launch_fused_pc<W, KH, 1, PF, 64, 4, 8>(a, st);   // one column block per consumer wave
+      return launch_fused_pc<W, KH, 1, PF, 64, 4, 4>(a, st);
+    } else {
+      // F = 512: the accumulators of both column blocks live across the K halves (8 consumers with one block each
+      // need 12 waves of <= 168 registers and spill); the two blocks walk K together instead
+      if (a.dout == 512) return launch_fused_pc<W, KH, 2, PF, 64, 4, 4>(a, st);
+      if (a.dout > 256) return launch_fused_tiles<W, KH, NCB, PF>(a, st);   // (a ragged second block: the one-role kernel)
+      return launch_fused_pc<W, KH, 1, PF, 64, 4, 4>(a, st);
+    }
+  } else {
+    return launch_fused_pc<W, KH, NCB, PF, 32, 4, 4>(a, st);
   }
 }
 

@@ -22,7 +22,8 @@ conflict map).  It placed as well but took memory torch could not see or reclaim
 reused ranges without stream tracking; it is gone.
 
 Environment: MP_PLACEMENT=off disables the check; MP_PLACE_MIN_MB the size from which outputs are checked (default
-1024: smaller ones live in L2 / Infinity Cache); MP_PLACE_TRIES the candidates per allocation (default 4);
+1024: smaller ones live in L2 / Infinity Cache); MP_PLACE_TRIES the candidates per allocation at most (default 8: on one
+box 7 of 10 successive blocks conflicted with the read tensor — four tries missed the good ones one time in four);
 MP_PLACE_ACCEPT the accepted slow-down of the probe against the fastest probe seen (default 0.05: good positions
 measure +0-4 %, conflicting ones +6-12 %).
 """
@@ -39,7 +40,7 @@ MiB = 1 << 20
 CHUNK = 256 * MiB                         # bytes of the candidate written per probe (reads: FAN x as much, past every cache)
 FAN = 10                                  # rows read per row written: the mean degree of the path's graphs
 MIN_BYTES = int(os.environ.get("MP_PLACE_MIN_MB", "1024")) * MiB
-TRIES = int(os.environ.get("MP_PLACE_TRIES", "4"))
+TRIES = int(os.environ.get("MP_PLACE_TRIES", "8"))
 ACCEPT = float(os.environ.get("MP_PLACE_ACCEPT", "0.05"))
 MEMO_ENTRIES = 4096
 
@@ -79,7 +80,7 @@ def _dev_state(device):
     st = _state.get(idx)
     if st is None:
         with _lock:
-            st = _state.setdefault(idx, {"t_min": {}, "memo": collections.OrderedDict(),
+            st = _state.setdefault(idx, {"t_min": {}, "memo": collections.OrderedDict(), "contrast": False,
                                          "stats": {"allocations": 0, "probed_pairs": 0, "memo_hits": 0, "retries": 0,
                                                    "probe_ms_total": 0.0}})
     return st
@@ -157,17 +158,27 @@ def empty_or_torch(shape, device, reads=(), dtype=torch.float32, tries=None, acc
         ms, chunk = pair_cost_ms(reads, t, st)
         if ms is None:
             return t
-        # the yardstick is the fastest probe seen FOR THESE READ TENSORS (another read tensor sits elsewhere and has
-        # another best); a read set seen for the first time has nothing to compare with and looks at three candidates
+        # Yardsticks: the fastest probe seen FOR THESE READ TENSORS (another read tensor sits elsewhere and has another
+        # best) and the fastest seen for ANY read tensor in this process.  The search ends when the best candidate is
+        # within `accept` of the first and `accept` + 1 % of the second — and, for a read set seen for the first time,
+        # after three candidates at least.  Until this process has seen two candidates of one read set differ by more
+        # than `accept` (a "contrast": both bands of the address hash observed, so the yardsticks are known to be from
+        # the fast one), a new read set whose candidates all look alike keeps looking, up to `tries`: on a box where 7
+        # of 10 blocks conflict, four alike candidates were all slow.
         rkey = (chunk,) + tuple((r.data_ptr(), r.numel() * r.element_size()) for r in reads if r is not None)
+        gkey = ("any", chunk)
         known = rkey in st["t_min"]
         st["t_min"][rkey] = min(st["t_min"].get(rkey, ms), ms)
-        gkey = ("any", chunk)               # ... and the fastest probe seen for ANY read tensor: a candidate far above it
-        st["t_min"][gkey] = min(st["t_min"].get(gkey, ms), ms)   # (the 12 % band) is worth the remaining tries even
-        best, best_ms, seen = t, ms, [ms]                        # when it is this read set's best so far
+        st["t_min"][gkey] = min(st["t_min"].get(gkey, ms), ms)
+        best, best_ms, seen = t, ms, [ms]
         held = []
-        while len(seen) < tries and (best_ms > (1.0 + accept) * st["t_min"][rkey] or (not known and len(seen) < 3)
-                                     or best_ms > (1.0 + 2.0 * max(accept, 0.0)) * st["t_min"][gkey]):
+        while len(seen) < tries:
+            if accept >= 0.0 and max(seen) > (1.0 + accept) * min(seen):
+                st["contrast"] = True
+            good = (best_ms <= (1.0 + accept) * st["t_min"][rkey]
+                    and best_ms <= (1.0 + max(accept, 0.0) + 0.01) * st["t_min"][gkey])
+            if good and (known or (len(seen) >= 3 and st["contrast"])):
+                break
             held.append(t)
             try:
                 t = torch.empty(shape, dtype=dtype, device=device)

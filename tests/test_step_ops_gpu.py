@@ -185,7 +185,9 @@ def test_bf16x3_split_follows_in_place_weight_updates(dev):
     ref2, _ = ops._raw_agg_dense(g, x, W.detach(), bf16x3=False)
     assert not torch.equal(out1, out2)
     from _tol import assert_close_rows
-    assert_close_rows(out2, ref2.double(), 2e-6, what="bf16x3 after an in-place re-initialisation")
+    # (the point is WHICH weights were used — a stale split is off by O(1) — so the bar is north_star's 1e-5 against the
+    # exact-fp32 product of the same launch, not the few-ulp agreement test_bf16x3_product_is_fp32_accurate measures)
+    assert_close_rows(out2, ref2.double(), 1e-5, what="bf16x3 after an in-place re-initialisation")
 
 
 def test_ginidconv_forward_reads_no_device_scalar_and_captures(dev):

@@ -1,6 +1,8 @@
 """Placement of large outputs (graphgym_amd/placement.py): outputs are ORDINARY torch allocations — checked against the
-tensors the launch reads with a timed copy, re-allocated on conflict — so torch keeps every byte under its own
-accounting, and the pair (read matrix, placed output) times within 3 % of the best pair torch's allocator offers."""
+tensors the launch reads with a timed probe, re-allocated on conflict — so torch keeps every byte under its own
+accounting, and the pair (read matrix, placed output) times within 3 % of the best pair torch's allocator offers.
+(The file sorts last on purpose: these tests allocate most of the card's memory, and the first one depends on which
+physical blocks the driver hands out — it should not stand between `-x` and the parity tests.)"""
 import gc
 
 import pytest
@@ -59,7 +61,8 @@ def test_placed_output_is_within_3pct_of_the_best_torch_block(dev):
     assert abs(_agg_ms(g, x, y2) - t_placed) <= 0.03 * t_placed
     if worst < 1.04 * best:
         pytest.skip(f"no placement effect on this box (best {best:.3f} ms, worst {worst:.3f} ms)")
-    assert t_placed <= 1.03 * best, f"placed {t_placed:.3f} ms vs best {best:.3f} / worst {worst:.3f} of 10 torch blocks: {times}"
+    assert t_placed <= 1.03 * best, (f"placed {t_placed:.3f} ms vs best {best:.3f} / worst {worst:.3f} of 10 torch blocks: "
+                                     f"{times}; probe: {info}")
 
 
 def test_placed_outputs_are_torch_memory(dev):
