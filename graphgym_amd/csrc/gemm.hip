@@ -521,6 +521,195 @@ __global__ __launch_bounds__(kBlock, 2) void dense_wgrad_wide_kernel(const float
   }
 }
 
+// The weight gradient at the hot shape (128 < F, d <= 256) with loading and multiplying on DIFFERENT waves (round 3).
+// The kernels above stage, split and multiply in the same waves: their MFMAs alone take 3.9 ms at 10^7 x 256 x 256 and
+// their loads + split + LDS stores alone 4.7 ms, but a wave that waits at a vector memory instruction issues no MFMAs
+// and the two add up to 10.5 ms.  Here a workgroup is 12 waves: waves 0-7 own the WHOLE 256 x 256
+// gradient (wave w: f rows 64 (w >> 1) .., d columns 128 (w & 1) .., 128 accumulator registers) and do nothing but
+// read fragments and issue MFMAs; waves 8-11 load the next 16-node tile of P and g (and y for the ReLU mask), split
+// it three ways and store the bf16 images — 48 KiB per stage, two stages — one workgroup barrier per tile.  P, g and y
+// are read exactly ONCE (the 256 x 128 tile read P once per d tile: FETCH 30.7 GB for 20.5 GB of operands).  One
+// workgroup per CU and one contiguous range of nodes per workgroup: at most kNumCU slabs, all of the same length.
+constexpr int WPC_MFMA_WAVES = 8, WPC_LOAD_WAVES = 4;
+constexpr int WPC_THREADS = 64 * (WPC_MFMA_WAVES + WPC_LOAD_WAVES);
+
+template <bool RELU>
+__global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const float* __restrict__ P, int64_t ldp,
+                                                                        const float* G, int64_t ldg,
+                                                                        const float* __restrict__ Y, int64_t ldy,
+                                                                        float* GM, int64_t ldgm, int64_t M, int32_t F,
+                                                                        int32_t d, int64_t chunk,
+                                                                        float* __restrict__ slabs,
+                                                                        float* __restrict__ bias_slabs) {
+  __shared__ __attribute__((aligned(16))) unsigned char Pimg[2][3][2][kPlaneBytes];   // [stage][plane][128-column half]
+  __shared__ __attribute__((aligned(16))) unsigned char Gimg[2][3][2][kPlaneBytes];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t c = blockIdx.x;
+  const int64_t mb = c * chunk;
+  const int64_t me = mb + chunk < M ? mb + chunk : M;
+  const int64_t ntiles = (me - mb + BK - 1) / BK;      // >= 1: the host launches ceil(M / chunk) workgroups
+
+  // Both roles run `nsteps` steps, a multiple of NSET: the tiles past the end of the range are all zero (rows >= me are
+  // zeroed at the split), so the loader loop is branch-free and unrolled over its register sets.
+  constexpr int NSET = RELU ? 2 : 3;         // tiles in flight per loader thread (16 / 24 registers each)
+  const int64_t nsteps = (ntiles + NSET - 1) / NSET * NSET;
+  if (wave >= WPC_MFMA_WAVES) {
+    // ------------------------------------------------ loaders ------------------------------------------------
+    const int lt = tid - 64 * WPC_MFMA_WAVES;
+    const int l_row = lt >> 4;               // 0..15: node row inside the tile
+    const int l_col = (lt & 15) * 8;         // 8 consecutive columns of each 128-column half
+    const bool do_bias = bias_slabs != nullptr;
+    float bs[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bs[h][i] = 0.f;
+    // (F % 8 == 0 and d % 8 == 0 — the host checks — so a thread's 8 columns are inside or outside as a whole; loads
+    // outside read column 0 / the last row of the range and are zeroed at the split: no branch around a load)
+    bool pin[2], gin[2];
+    int pcol[2], gcol[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int fc = 128 * h + l_col;
+      pin[h] = fc < F; gin[h] = fc < d;
+      pcol[h] = pin[h] ? fc : 0; gcol[h] = gin[h] ? fc : 0;
+    }
+    f32x4 rp[NSET][2][2], rg[NSET][2][2], ry[RELU ? NSET : 1][2][2];
+    auto fetch = [&](int s, int64_t tile) {            // s: compile-time after unrolling
+      int64_t m = mb + tile * BK + l_row;
+      m = m < me ? m : me - 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float* ps = P + m * ldp + pcol[h];
+        rp[s][h][0] = *reinterpret_cast<const f32x4*>(ps);
+        rp[s][h][1] = *reinterpret_cast<const f32x4*>(ps + 4);
+        const float* gs = G + m * ldg + gcol[h];
+        rg[s][h][0] = *reinterpret_cast<const f32x4*>(gs);
+        rg[s][h][1] = *reinterpret_cast<const f32x4*>(gs + 4);
+        if constexpr (RELU) {
+          const float* ys = Y + m * ldy + gcol[h];
+          ry[s][h][0] = *reinterpret_cast<const f32x4*>(ys);
+          ry[s][h][1] = *reinterpret_cast<const f32x4*>(ys + 4);
+        }
+      }
+    };
+    auto stash = [&](int s, int64_t tile, int buf) {
+      const int off = swz_off(l_row, l_col >> 3);
+      const int64_t m = mb + tile * BK + l_row;
+      const bool ok = m < me;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float pv[8], gv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          pv[i] = (ok && pin[h]) ? rp[s][h][i >> 2][i & 3] : 0.f;
+          gv[i] = (ok && gin[h]) ? rg[s][h][i >> 2][i & 3] : 0.f;
+          if constexpr (RELU) gv[i] = ry[s][h][i >> 2][i & 3] > 0.f ? gv[i] : 0.f;
+        }
+        if constexpr (RELU) {
+          if (GM != nullptr && ok && gin[h]) {
+            float* go = GM + m * ldgm + gcol[h];
+            *reinterpret_cast<f32x4*>(go) = f32x4{gv[0], gv[1], gv[2], gv[3]};
+            *reinterpret_cast<f32x4*>(go + 4) = f32x4{gv[4], gv[5], gv[6], gv[7]};
+          }
+        }
+        bf16x8 sp[3];
+        split3_bf16(pv, sp[0], sp[1], sp[2]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(&Pimg[buf][pl][h][off]) = sp[pl];
+        bf16x8 sg[3];
+        split3_bf16(gv, sg[0], sg[1], sg[2]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(&Gimg[buf][pl][h][off]) = sg[pl];
+        if (do_bias) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) bs[h][i] += gv[i];
+        }
+      }
+    };
+    // tile k lives in register set k % NSET from NSET steps before its step; during step t (the MFMA waves read stage
+    // t & 1) tile t + 1 is split into stage (t + 1) & 1 and tile t + 1 + NSET is requested into the set it leaves
+#pragma unroll
+    for (int k = 0; k < NSET; ++k) fetch(k, k);
+    stash(0, 0, 0);
+    fetch(0, NSET);
+    __syncthreads();                                   // stage 0 holds tile 0
+    for (int64_t base = 0; base < nsteps; base += NSET) {
+#pragma unroll
+      for (int u = 0; u < NSET; ++u) {
+        const int64_t t = base + u;
+        const int sidx = (u + 1) % NSET;
+        stash(sidx, t + 1, (int)((t + 1) & 1));
+        fetch(sidx, t + 1 + NSET);
+        __syncthreads();                               // step t done
+      }
+    }
+    if (do_bias) {   // 16 threads hold partial sums of the same 8 columns: add them in row order through LDS
+      float (*red)[256] = reinterpret_cast<float (*)[256]>(&Pimg[0][0][0][0]);      // [16][256] floats = 16 KiB
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        *reinterpret_cast<f32x4*>(&red[l_row][128 * h + l_col]) = f32x4{bs[h][0], bs[h][1], bs[h][2], bs[h][3]};
+        *reinterpret_cast<f32x4*>(&red[l_row][128 * h + l_col + 4]) = f32x4{bs[h][4], bs[h][5], bs[h][6], bs[h][7]};
+      }
+    }
+    __syncthreads();                                   // (the MFMA waves pass it on their way to the slab stores)
+    if (do_bias && lt < 256 && lt < d) {
+      const float (*red)[256] = reinterpret_cast<const float (*)[256]>(&Pimg[0][0][0][0]);
+      float sacc = 0.f;
+#pragma unroll
+      for (int r = 0; r < BK; ++r) sacc += red[r][lt];
+      bias_slabs[c * (int64_t)d + lt] = sacc;
+    }
+  } else {
+    // ------------------------------------------------ MFMA waves ------------------------------------------------
+    const int wf = wave >> 1, wd = wave & 1;
+    const int fr = lane & 31, fk = lane >> 5;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __syncthreads();                                   // stage 0 holds tile 0
+    for (int64_t t = 0; t < nsteps; ++t) {
+      const int buf = (int)(t & 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf16x8 as[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) as[pl] = tr_read8(Pimg[buf][pl][wf >> 1], (wf & 1) * 64 + i * 32, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16x8 b3[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) b3[pl] = tr_read8(Gimg[buf][pl][wd], j * 32, lane);
+          mfma6(acc[i][j], as, b3);
+          // (one fragment set at a time: hoisting the reads of all four d tiles costs 121 registers of scratch; the
+          // SIMD's other MFMA wave covers the LDS latency)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();                                 // step t done: the loaders may overwrite this stage
+    }
+    __syncthreads();                                   // (the loaders' bias reduction)
+    float* slab = slabs + c * (int64_t)F * d;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = wd * 128 + j * 32 + fr;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wf * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+          if (row < F && col < d) slab[(int64_t)row * d + col] = acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
 // Narrow inputs (F <= 8: the reference's synthetic datasets carry node_feature = [1.], so the first layer of every
 // model has F = 1): dW[f, :] = sum_m P[m, f] g[m, :] is a handful of weighted column sums — HBM-bound, no use for
 // 128 x 128 MFMA tiles (17.9 ms at 10^7 x 1 x 256 through them).  A thread owns one output column over a chunk of
@@ -773,6 +962,18 @@ static int64_t wgrad_chunk(int64_t M, int32_t F, int32_t d) {
 
 static bool al16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
 
+// the producer/consumer weight gradient: one contiguous node range per workgroup, one workgroup per CU (never more
+// chunks than wgrad_chunk gives: pc_chunk >= 4096 and >= M / kNumCU)
+static int64_t wgrad_pc_chunk(int64_t M) {
+  int64_t c = ceil_div(M, (int64_t)kNumCU);
+  c = ceil_div(c, (int64_t)BK) * BK;
+  return c < 4096 ? 4096 : c;
+}
+static bool wgrad_no_pc() {   // MP_WGRAD_PC=0: the 256 x 128 tile kernel (A/B studies), read per call
+  const char* e = getenv("MP_WGRAD_PC");
+  return e && e[0] == '0';
+}
+
 }  // namespace mp
 
 using namespace mp;
@@ -870,6 +1071,27 @@ static int wgrad_common(const float* P, int64_t ldp, const float* G, int64_t ldg
     if (dbias) {
       hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)d * 16)), dim3(kBlock), 0, st,
                          (const float*)bias_slabs, n_chunk, (int64_t)d, dbias);
+      MP_LAUNCH_CHECK();
+    }
+    return MP_OK;
+  }
+  if (vec && F > 128 && F <= 256 && d > 128 && d <= 256 && F % 8 == 0 && d % 8 == 0 && !wgrad_no_pc()) {   // loaders + MFMA waves, the whole gradient per workgroup
+    const int64_t pc_chunk = wgrad_pc_chunk(M);
+    const int64_t n_pc = ceil_div(M, pc_chunk);            // <= n_chunk: the workspace of mp_dense_wgrad_ws_bytes holds it
+    float* pc_bias = dbias ? (float*)ws + (size_t)n_pc * F * d : nullptr;
+    if (Y)
+      hipLaunchKernelGGL(dense_wgrad_pc_kernel<true>, dim3((unsigned)n_pc), dim3(WPC_THREADS), 0, st, P, ldp, G, ldg, Y,
+                         ldy, GM, ldgm, M, F, d, pc_chunk, (float*)ws, pc_bias);
+    else
+      hipLaunchKernelGGL(dense_wgrad_pc_kernel<false>, dim3((unsigned)n_pc), dim3(WPC_THREADS), 0, st, P, ldp, G, ldg, Y,
+                         ldy, GM, ldgm, M, F, d, pc_chunk, (float*)ws, pc_bias);
+    MP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)F * d * 16)), dim3(kBlock), 0, st, (const float*)ws,
+                       n_pc, (int64_t)F * d, dW);
+    MP_LAUNCH_CHECK();
+    if (dbias) {
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)d * 16)), dim3(kBlock), 0, st,
+                         (const float*)pc_bias, n_pc, (int64_t)d, dbias);
       MP_LAUNCH_CHECK();
     }
     return MP_OK;

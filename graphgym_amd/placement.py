@@ -22,8 +22,12 @@ conflict map).  It placed as well but took memory torch could not see or reclaim
 reused ranges without stream tracking; it is gone.
 
 Environment: MP_PLACEMENT=off disables the check; MP_PLACE_MIN_MB the size from which outputs are checked (default
-1024: smaller ones live in L2 / Infinity Cache); MP_PLACE_TRIES the candidates per allocation at most (default 8: on one
-box 7 of 10 successive blocks conflicted with the read tensor — four tries missed the good ones one time in four);
+1024: smaller ones live in L2 / Infinity Cache); MP_PLACE_TRIES the candidates per allocation at most (default 4);
+MP_PLACE_EXPLORE the candidates the first two read sets of a process may look at while no two candidates have differed
+yet (default 8: on one box 7 of 10 successive blocks conflicted with the read tensor, and four candidates that all look
+alike can all be slow; every further candidate is held while the next is allocated and churns torch's cache — in a
+training loop that means new buffer pairs and new probes in later steps — so the wide search is for the first
+allocations only);
 MP_PLACE_ACCEPT the accepted slow-down of the probe against the fastest probe seen (default 0.05: good positions
 measure +0-4 %, conflicting ones +6-12 %).
 """
@@ -40,7 +44,9 @@ MiB = 1 << 20
 CHUNK = 256 * MiB                         # bytes of the candidate written per probe (reads: FAN x as much, past every cache)
 FAN = 10                                  # rows read per row written: the mean degree of the path's graphs
 MIN_BYTES = int(os.environ.get("MP_PLACE_MIN_MB", "1024")) * MiB
-TRIES = int(os.environ.get("MP_PLACE_TRIES", "8"))
+TRIES = int(os.environ.get("MP_PLACE_TRIES", "4"))
+EXPLORE_TRIES = int(os.environ.get("MP_PLACE_EXPLORE", "8"))   # candidates for the first read sets of a process, see below
+EXPLORE_SETS = 2
 ACCEPT = float(os.environ.get("MP_PLACE_ACCEPT", "0.05"))
 MEMO_ENTRIES = 4096
 
@@ -80,7 +86,7 @@ def _dev_state(device):
     st = _state.get(idx)
     if st is None:
         with _lock:
-            st = _state.setdefault(idx, {"t_min": {}, "memo": collections.OrderedDict(), "contrast": False,
+            st = _state.setdefault(idx, {"t_min": {}, "memo": collections.OrderedDict(), "contrast": False, "explore_left": EXPLORE_SETS,
                                          "stats": {"allocations": 0, "probed_pairs": 0, "memo_hits": 0, "retries": 0,
                                                    "probe_ms_total": 0.0}})
     return st
@@ -109,28 +115,29 @@ def pair_cost_ms(reads, t, st=None):
     if not big or tb < CHUNK or t.data_ptr() % 16:
         return None, None
     chunk = CHUNK
-    key = (tuple(big), t.data_ptr(), tb)
     memo = st["memo"]
-    hit = memo.get(key)
-    if hit is not None:
-        memo.move_to_end(key)
-        st["stats"]["memo_hits"] += 1
-        return hit, chunk
     total, wsum, cnt = 0.0, 0.0, 0
-    for ptr, nb in big:
-        acc = 0.0
-        pos = _samples(t.data_ptr(), tb, chunk)
-        for dst in pos:
-            acc += min(_probe_gather(ptr, nb // 1024 * 1024, dst, chunk, 1) for _ in range(2))
-            cnt += 1
-        total += nb * acc / len(pos)
+    for ptr, nb in big:                      # remembered per (read buffer, candidate buffer): launches share buffers
+        key = (ptr, nb, t.data_ptr(), tb)
+        acc = memo.get(key)
+        if acc is not None:
+            memo.move_to_end(key)
+            st["stats"]["memo_hits"] += 1
+        else:
+            acc = 0.0
+            pos = _samples(t.data_ptr(), tb, chunk)
+            for dst in pos:
+                acc += min(_probe_gather(ptr, nb // 1024 * 1024, dst, chunk, 1) for _ in range(2))
+            acc /= len(pos)
+            cnt += len(pos)
+            memo[key] = acc
+            if len(memo) > MEMO_ENTRIES:
+                memo.popitem(last=False)
+        total += nb * acc
         wsum += nb
     ms = total / wsum
     st["stats"]["probed_pairs"] += cnt
     st["stats"]["probe_ms_total"] += 4.0 * ms * cnt          # two trials, each one untimed + one timed launch
-    memo[key] = ms
-    if len(memo) > MEMO_ENTRIES:
-        memo.popitem(last=False)
     return ms, chunk
 
 
@@ -150,6 +157,7 @@ def empty_or_torch(shape, device, reads=(), dtype=torch.float32, tries=None, acc
     if (streaming or nbytes < MIN_BYTES or not enabled() or not t.is_cuda or not reads
             or torch.cuda.is_current_stream_capturing()):     # a probe synchronises: never under HIP-graph capture
         return t
+    tries_given = tries
     tries = TRIES if tries is None else int(tries)
     accept = ACCEPT if accept is None else float(accept)
     st = _dev_state(t.device)
@@ -160,24 +168,28 @@ def empty_or_torch(shape, device, reads=(), dtype=torch.float32, tries=None, acc
             return t
         # Yardsticks: the fastest probe seen FOR THESE READ TENSORS (another read tensor sits elsewhere and has another
         # best) and the fastest seen for ANY read tensor in this process.  The search ends when the best candidate is
-        # within `accept` of the first and `accept` + 1 % of the second — and, for a read set seen for the first time,
-        # after three candidates at least.  Until this process has seen two candidates of one read set differ by more
-        # than `accept` (a "contrast": both bands of the address hash observed, so the yardsticks are known to be from
-        # the fast one), a new read set whose candidates all look alike keeps looking, up to `tries`: on a box where 7
-        # of 10 blocks conflict, four alike candidates were all slow.
+        # within `accept` of the first and 2 x `accept` of the second — for a read set seen for the first time after
+        # three candidates at least.  While this process has not yet seen two candidates of one read set differ by more
+        # than `accept` (a "contrast": both bands of the address hash observed, so the yardsticks are known to come
+        # from the fast one), its first EXPLORE_SETS new read sets keep looking until they see one, up to EXPLORE_TRIES.
         rkey = (chunk,) + tuple((r.data_ptr(), r.numel() * r.element_size()) for r in reads if r is not None)
         gkey = ("any", chunk)
         known = rkey in st["t_min"]
         st["t_min"][rkey] = min(st["t_min"].get(rkey, ms), ms)
         st["t_min"][gkey] = min(st["t_min"].get(gkey, ms), ms)
+        explore = (not known and not st["contrast"] and st["explore_left"] > 0 and tries_given is None and accept >= 0.0)
+        if explore:
+            st["explore_left"] -= 1
+            tries = max(tries, EXPLORE_TRIES)
         best, best_ms, seen = t, ms, [ms]
         held = []
         while len(seen) < tries:
-            if accept >= 0.0 and max(seen) > (1.0 + accept) * min(seen):
+            spread = accept >= 0.0 and max(seen) > (1.0 + accept) * min(seen)
+            if spread:
                 st["contrast"] = True
             good = (best_ms <= (1.0 + accept) * st["t_min"][rkey]
-                    and best_ms <= (1.0 + max(accept, 0.0) + 0.01) * st["t_min"][gkey])
-            if good and (known or (len(seen) >= 3 and st["contrast"])):
+                    and best_ms <= (1.0 + 2.0 * max(accept, 0.0)) * st["t_min"][gkey])
+            if good and (known or (len(seen) >= 3 and (spread or not explore))):
                 break
             held.append(t)
             try:

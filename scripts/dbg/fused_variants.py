@@ -10,7 +10,10 @@ dev = torch.device("cuda:0")
 n, d = int(os.environ.get("N", "10000000")), int(os.environ.get("DIM", "256"))
 dout = int(os.environ.get("DOUT", str(d)))
 variants = os.environ.get("VARIANTS", "1,2,3,9").split(",")
-g = ga.CSRGraph.from_edge_index(graphgen.ba_edge_index(n, 5, 12345, device=dev), n, add_self_loops=True).gcn_norm("row")
+SELF = bool(os.environ.get("SELF"))          # GIN's shape: unweighted sum + (1 + eps) x
+g = ga.CSRGraph.from_edge_index(graphgen.ba_edge_index(n, 5, 12345, device=dev), n, add_self_loops=not SELF)
+if not SELF:
+    g = g.gcn_norm("row")
 g.plan()
 torch.cuda.empty_cache()
 x = torch.empty((n, d), device=dev).uniform_(-1, 1)
@@ -22,7 +25,8 @@ Wsp = ops._split_bf16_t(W)
 L = lib()
 
 def once(keepP):
-    check(L.mp_agg_dense_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val), n, 0, ptr(x), x.stride(0), d, None, 0, 0.0, ptr(W), W.stride(0), dout,
+    check(L.mp_agg_dense_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val) if g.val is not None else None, n, 0, ptr(x), x.stride(0), d,
+                             ptr(x) if SELF else None, x.stride(0) if SELF else 0, 1.0 if SELF else 0.0, ptr(W), W.stride(0), dout,
                              ptr(b), 1, None, ptr(P) if keepP else None, P.stride(0) if keepP else 0, ptr(y), y.stride(0), ptr(Wsp), _stream()))
 
 def t(keepP, reps=5):
@@ -52,4 +56,4 @@ ops._raw_spmm(g, x, 0, out=y)
 e0.record()
 for _ in range(5): ops._raw_spmm(g, x, 0, out=y)
 e1.record(); torch.cuda.synchronize()
-print(json.dumps({"n": n, "d": d, "dout": dout, "plain_agg_ms": round(e0.elapsed_time(e1) / 5, 3), "variants": res}))
+print(json.dumps({"self_term": SELF, "n": n, "d": d, "dout": dout, "plain_agg_ms": round(e0.elapsed_time(e1) / 5, 3), "variants": res}))

@@ -52,7 +52,7 @@ def test_placed_output_is_within_3pct_of_the_best_torch_block(dev):
     t_placed = _agg_ms(g, x, y)
     after = placement.stats(dev)
     assert after["allocations"] == before["allocations"] + 1 and after["probed_pairs"] > before["probed_pairs"]
-    assert 1 <= len(info["candidates_ms"]) <= placement.TRIES and info["chosen_ms"] == min(info["candidates_ms"])
+    assert 1 <= len(info["candidates_ms"]) <= max(placement.TRIES, placement.EXPLORE_TRIES) and info["chosen_ms"] == min(info["candidates_ms"])
     # the same request again: same blocks from torch's cache, so the probes come from the memo (no timed copies)
     del y
     y2 = placement.empty_or_torch((n, d), dev, reads=(x,))
