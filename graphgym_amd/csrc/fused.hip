@@ -1217,14 +1217,19 @@ static int launch_fused(const FusedArgs& a, hipStream_t st) {
   const int v = fused_variant();
   if (v == 9) return launch_fused_tiles<W, KH, NCB, PF>(a, st);
   if constexpr (W == 4) {
-    if (v == 1) return launch_fused_pc<W, KH, NCB, PF, 32, 4, 4>(a, st);
     if constexpr (KH == 1) {
+      if (v == 1) return launch_fused_pc<W, KH, NCB, PF, 32, 4, 4>(a, st);
       if (v == 2) return launch_fused_pc<W, KH, NCB, PF, 64, 8, 4>(a, st);
       if (v == 4) return launch_fused_pc<W, KH, NCB, PF, 64, 2, 4>(a, st);
       if (v == 5) return launch_fused_pc<W, KH, NCB, PF, 64, 6, 4>(a, st);
     }
     if (v == 3) return launch_fused_pc<W, KH, NCB, PF, 64, 4, 4>(a, st);
     if constexpr (KH == 1) {
+      // With a self term (GIN's (1 + eps) x) the producers first load the tile's own rows and a third barrier separates
+      // that from the runs: the 64-row kernel loses its edge (24.1 / 26.1 ms, out only / aggregated rows kept, against
+      // 23.75 / 25.3 for 32-row tiles and 23.8 / 24.9 for the one-role kernel; profiles/r03_fused_variants.json)
+      if (a.S != nullptr && v == 0 && a.dout <= 256)
+        return a.P != nullptr ? launch_fused_tiles<W, KH, NCB, PF>(a, st) : launch_fused_pc<W, KH, NCB, PF, 32, 4, 4>(a, st);
       if (a.dout > 256) return launch_fused_pc<W, KH, 1, PF, 64, 4, 8>(a, st);   // one column block per consumer wave
       return launch_fused_pc<W, KH, 1, PF, 64, 4, 4>(a, st);
     } else {

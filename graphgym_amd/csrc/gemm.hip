@@ -530,6 +530,9 @@ __global__ __launch_bounds__(kBlock, 2) void dense_wgrad_wide_kernel(const float
 // it three ways and store the bf16 images — 48 KiB per stage, two stages — one workgroup barrier per tile.  P, g and y
 // are read exactly ONCE (the 256 x 128 tile read P once per d tile: FETCH 30.7 GB for 20.5 GB of operands).  One
 // workgroup per CU and one contiguous range of nodes per workgroup: at most kNumCU slabs, all of the same length.
+#ifndef MP_WPC_ABL
+#define MP_WPC_ABL 0   // ablation bits (timing studies, wrong results): 1 loaders idle, 2 no MFMAs, 16 with 1: loads only
+#endif
 constexpr int WPC_MFMA_WAVES = 8, WPC_LOAD_WAVES = 4;
 constexpr int WPC_THREADS = 64 * (WPC_MFMA_WAVES + WPC_LOAD_WAVES);
 
@@ -640,8 +643,12 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
       for (int u = 0; u < NSET; ++u) {
         const int64_t t = base + u;
         const int sidx = (u + 1) % NSET;
+#if !(MP_WPC_ABL & 1)
         stash(sidx, t + 1, (int)((t + 1) & 1));
         fetch(sidx, t + 1 + NSET);
+#elif (MP_WPC_ABL & 16)
+        fetch(sidx, t + 1 + NSET);                       // (loads only: no split, no LDS stores)
+#endif
         __syncthreads();                               // step t done
       }
     }
@@ -684,8 +691,12 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
         for (int j = 0; j < 4; ++j) {
           bf16x8 b3[3];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) b3[pl] = tr_read8(Gimg[buf][pl][wd], j * 32, lane);
+          for (int pl = 0; pl < 3; ++pl) b3[pl] = tr_read8(Gimg[buf][pl][wd], (MP_WPC_ABL & 4) ? 0 : j * 32, lane);
+#if !(MP_WPC_ABL & 2)
           mfma6(acc[i][j], as, b3);
+#else
+          asm volatile("" ::"v"(b3[0]), "v"(b3[1]), "v"(b3[2]), "v"(as[0]), "v"(as[1]), "v"(as[2]));
+#endif
           // (one fragment set at a time: hoisting the reads of all four d tiles costs 121 registers of scratch; the
           // SIMD's other MFMA wave covers the LDS latency)
           __builtin_amdgcn_sched_barrier(0);

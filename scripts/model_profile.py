@@ -1,3 +1,4 @@
+import os
 """One TF-path model's training step at 10M nodes under rocprofv3 (KIND=sage|gin|gcn...)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +18,6 @@ ids = torch.arange(0, n, 100, device=dev)
 def fl():
     inputs = [x, ei] + ([ids] if model.with_id else [])
     return H.tfg_loss(model(inputs, holder=holder), idx, labels, model.kernel_parameters())
-for _ in range(5):      # scripts/step_window.py takes the last two
+for _ in range(int(os.environ.get("STEPS", "5"))):      # scripts/step_window.py takes the last two
     H.train_step(model, opt, fl)
 torch.cuda.synchronize()

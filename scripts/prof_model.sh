@@ -8,8 +8,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -- python3 $REPO/scripts/model_profile.py > $OUT/log.txt 2>&1 || { tail -5 $OUT/log.txt; exit 1; }
 find $OUT/t -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/stats.csv
-# whole steps only: the window between the 3rd and 5th launch of the loss's forward kernel (2 of the 5 steps)
-find $OUT/t -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 $REPO/scripts/step_window.py {} softmax_ce_rows_kernel 3 5 > $OUT/steady.csv
+# whole steps only: the window between the (STEPS-2)th and STEPS-th launch of the loss's forward kernel (the last 2 of STEPS steps, default 5)
+find $OUT/t -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 $REPO/scripts/step_window.py {} softmax_ce_rows_kernel $((${STEPS:-5} - 2)) ${STEPS:-5} > $OUT/steady.csv
 # the time-ordered launches of the first 400 ms after the graph build, to tell first-call effects from steady state
 find $OUT/t -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 $REPO/scripts/trace_head.py {} > $OUT/first_launches.txt
 find $OUT/t -type f -delete

@@ -18,8 +18,8 @@ wall = float(rows[0]["WindowNs"]) / steps / 1e6
 worst = max(rows, key=lambda r: float(r["MaxNs"]) / max(float(r["MinNs"]), 1.0) if float(r["MaxNs"]) > 2e6 else 0)
 path = os.path.join(ROOT, "profiles", f"{tag}_{kind}_step_kernels.csv")
 with open(path, "w", newline="") as f:
-    f.write(f'"# rocprofv3 --kernel-trace of scripts/model_profile.py KIND={kind} (N=1e7, d=256): the last {steps} of 5 '
-            f'training steps (scripts/step_window.py), {total:.1f} ms of kernels per step in {wall:.1f} ms of wall time '
+    f.write(f'"# rocprofv3 --kernel-trace of scripts/model_profile.py KIND={kind} (N=1e7, d=256): the last {steps} '
+            f'training steps of the run (scripts/step_window.py), {total:.1f} ms of kernels per step in {wall:.1f} ms of wall time '
             f'per step under the profiler; largest max/min spread of a >2 ms kernel: '
             f'{float(worst["MaxNs"]) / float(worst["MinNs"]):.2f}x"\n')
     w = csv.writer(f)
