@@ -662,7 +662,7 @@ __device__ __forceinline__ void mfma_rows(const float (*T)[FH + 4], const float*
 // NC consumer waves, 64 output columns each: 4 for dout <= 256; 8 for wider outputs, where four consumers — two column
 // blocks each, a W fragment round trip of ~1 us per K group and block behind the CU's gathers — take longer than the
 // producers need for the next tile and the layer becomes consumer-bound (F = dout = 512: 53.2 ms with 4, XX with 8).
-template <int W, bool WEIGHTED, int U, int KH, int NCB, int PF, bool NT_OUT, bool BF16X3, int TR, int NP, int NC>
+template <int W, bool WEIGHTED, int U, int KH, int NCB, int PF, bool NT_OUT, bool BF16X3, int TR, int NP, int NC, bool HAS_S>
 __global__ __launch_bounds__((NP + NC) * kWave, TR == 64 ? (NP + NC + 3) / 4 : 4)
 void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32_t n_tiles) {
   constexpr int FH = kWave * W;
@@ -700,7 +700,8 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
   int nxt_kh = KH == 1 ? 0 : 1;
   int prev_tile = -1, prev_kh = 0;            // the item the consumers work on
   int buf = 0;
-  const bool has_s = a.S != nullptr;          // the self term initialises the tile (GIN's (1 + eps) x): one more barrier
+  constexpr bool has_s = HAS_S;               // the self term (GIN's (1 + eps) x) initialises the tile
+  constexpr int RPW = TR / NP;                // ... each producer wave RPW of its rows, requested one item ahead
 
   // The two roles run SEPARATE loops over the same item sequence (the workgroup barriers b0 / b1 / b2 pair up by
   // count: s_barrier counts arriving waves, wherever they are in the code), so the registers of the gathers in
@@ -760,6 +761,37 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
         if (WEIGHTED) wvF = a.val[min(es + lane, ee - 1)];
       }
     }
+    // Self term: wave w holds rows RPW w .. RPW w + RPW - 1 of the NEXT item's tile of S in registers from the top of
+    // the current item (requested a whole item ahead: no latency left) and writes them, scaled, into the other buffer
+    // between the barriers that close the current item — after b1 the consumers are done with that buffer, and b2
+    // stands between these stores and the runs that add into them.  (Round 2 / the first form of this kernel loaded
+    // the rows at the top of their own item and paid a third barrier per item.)
+    float sv[has_s ? RPW : 1][W];
+    auto own_rows_load = [&](int tile, int kh) {
+      const int NR0 = tile * kTileRows + wave * RPW;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int row = min(NR0 + i, a.N - 1);
+        load_vec<W>(a.S + (int64_t)row * a.lds + kh * FH + lane * W, sv[i]);
+      }
+    };
+    auto own_rows_store = [&](int tile, int b) {
+      const int NR0 = tile * kTileRows + wave * RPW;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        float v[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = NR0 + i < a.N ? sv[i][k] * a.self_scale : 0.f;
+        store_vec<W>(&T[b][wave * RPW + i][lane * W], v);
+      }
+    };
+    if constexpr (has_s) {
+      if (cur_tile >= 0) {
+        own_rows_load(cur_tile, cur_kh);
+        own_rows_store(cur_tile, 0);
+        __syncthreads();   // b0, once: the first tile initialised (the consumers pass it too)
+      }
+    }
     int it = 0;
     while (cur_tile >= 0 || prev_tile >= 0) {
       if (wave == 0) PC_T(0);
@@ -782,18 +814,6 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
           defer_l[buf][lane] = defer_l[buf ^ 1][lane];
         }
         if (lane == 0) carry_row[wave] = cont ? first_rl : -1;
-        if (has_s) {
-          constexpr int VPR = FH / 4;
-          for (int i = tid; i < kTileRows * VPR; i += kPcGather * kWave) {
-            const int m = i / VPR, c = (i % VPR) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (R0 + m < R1) {
-              v = *reinterpret_cast<const f32x4*>(a.S + (int64_t)(R0 + m) * a.lds + k0 + c);
-              v *= a.self_scale;
-            }
-            *reinterpret_cast<f32x4*>(&T[buf][m][c]) = v;
-          }
-        }
       }
       if (nxt_tile >= 0) {   // the next item's run and its first index batch: on their way while this item runs
         if (nxt_kh == 0) {
@@ -806,8 +826,8 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
           cv1 = a.col[min(es1 + lane, ee1 - 1)];
           if (WEIGHTED) wv1 = a.val[min(es1 + lane, ee1 - 1)];
         }
+        if constexpr (has_s) own_rows_load(nxt_tile, nxt_kh);   // written into the other buffer once the consumers leave it (b1)
       }
-      if (has_s) __syncthreads();   // b0 (self term only): buffer `buf` initialised before the runs add into it
 
       {
         // ================= producers: phase A of (cur_tile, cur_kh) =================
@@ -913,6 +933,9 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
       __syncthreads();   // b1: every producer run is reduced into `buf` (and the consumers are done with buf ^ 1)
       if (wave == 0) PC_T(2);
 
+      if constexpr (has_s) {
+        if (nxt_tile >= 0) own_rows_store(nxt_tile, buf ^ 1);
+      }
       // ---- carries: a row cut by run boundaries gets its later parts in wave order ----
       if (cur_tile >= 0 && tid < FH) {
 #pragma unroll
@@ -1027,7 +1050,7 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
             const __bf16* w0 = a.Wsp + ((int64_t)kk * a.dout + ccol) * 8;
             // (64-row tiles, 4 consumers: 169 of 256 registers — room for fragments two K groups ahead: 21.09 -> 20.93 ms,
             // aggregated rows kept 23.03 -> 22.65 ms; three ahead: the same)
-            if constexpr (TR == 64 && NC == 4) mfma_rows_bf16x3_ring<FH, RB, MP_W_RING>(T[pb], w0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, acc, fr, kk);
+            if constexpr (TR == 64 && NC == 4 && NP == 4) mfma_rows_bf16x3_ring<FH, RB, MP_W_RING>(T[pb], w0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, acc, fr, kk);
             else mfma_rows_bf16x3<FH, RB, 1>(T[pb], w0, 0, (int64_t)a.dout * 16, (int64_t)a.dout * a.ldws, acc, fr, kk);
           } else {
             const float* __restrict__ wp = a.Wm + (int64_t)(4 * kk) * a.ldw + ccol;
@@ -1131,10 +1154,9 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
       ++it;
     };
     if (cur_tile >= 0) {
-      if (has_s) __syncthreads();   // b0 of the first item: nothing to consume yet
+      if (has_s) __syncthreads();   // b0, once (the producers initialise the first tile's buffer)
       sync_advance();
       while (prev_tile >= 0) {      // (the producers run the same number of items)
-        if (has_s) __syncthreads();
         if (cw == 0) PC_T(4);
         work(prev_kh);
         sync_advance();
@@ -1182,8 +1204,8 @@ static int pc_counter(unsigned int** ctr, hipStream_t st) {
   return MP_OK;
 }
 
-template <int W, int KH, int NCB, int PF, int TR, int NP, int NC>
-static int launch_fused_pc(const FusedArgs& a, hipStream_t st) {
+template <int W, int KH, int NCB, int PF, int TR, int NP, int NC, bool HAS_S>
+static int launch_fused_pc_s(const FusedArgs& a, hipStream_t st) {
   const int64_t n_tiles = ceil_div(a.N, TR);
   unsigned int* ctr = nullptr;
   const int rc = pc_counter(&ctr, st);
@@ -1192,14 +1214,22 @@ static int launch_fused_pc(const FusedArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident)), block((NP + NC) * kWave);
   const int32_t nt = (int32_t)n_tiles;
   if (a.Wsp != nullptr) {
-    if (a.val) hipLaunchKernelGGL((agg_dense_pc_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, true, TR, NP, NC>), grid, block, 0, st, a, ctr, nt);
-    else hipLaunchKernelGGL((agg_dense_pc_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, true, TR, NP, NC>), grid, block, 0, st, a, ctr, nt);
+    if (a.val) hipLaunchKernelGGL((agg_dense_pc_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, true, TR, NP, NC, HAS_S>), grid, block, 0, st, a, ctr, nt);
+    else hipLaunchKernelGGL((agg_dense_pc_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, true, TR, NP, NC, HAS_S>), grid, block, 0, st, a, ctr, nt);
   } else {
-    if (a.val) hipLaunchKernelGGL((agg_dense_pc_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, false, TR, NP, NC>), grid, block, 0, st, a, ctr, nt);
-    else hipLaunchKernelGGL((agg_dense_pc_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, false, TR, NP, NC>), grid, block, 0, st, a, ctr, nt);
+    if (a.val) hipLaunchKernelGGL((agg_dense_pc_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, false, TR, NP, NC, HAS_S>), grid, block, 0, st, a, ctr, nt);
+    else hipLaunchKernelGGL((agg_dense_pc_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, false, TR, NP, NC, HAS_S>), grid, block, 0, st, a, ctr, nt);
   }
   MP_LAUNCH_CHECK();
   return MP_OK;
+}
+
+// SELF_OK: the self-term form of this shape is built (it holds TR / NP rows of S in registers: not every shape has them)
+template <int W, int KH, int NCB, int PF, int TR, int NP, int NC, bool SELF_OK = false>
+static int launch_fused_pc(const FusedArgs& a, hipStream_t st) {
+  if (a.S == nullptr) return launch_fused_pc_s<W, KH, NCB, PF, TR, NP, NC, false>(a, st);
+  if constexpr (SELF_OK) return launch_fused_pc_s<W, KH, NCB, PF, TR, NP, NC, true>(a, st);
+  else return launch_fused_tiles<W, KH, NCB, PF>(a, st);
 }
 
 static int fused_variant() {   // MP_FUSED_VARIANT (studies: scripts/dbg/fused_variants.py), read per launch
@@ -1218,29 +1248,25 @@ static int launch_fused(const FusedArgs& a, hipStream_t st) {
   if (v == 9) return launch_fused_tiles<W, KH, NCB, PF>(a, st);
   if constexpr (W == 4) {
     if constexpr (KH == 1) {
-      if (v == 1) return launch_fused_pc<W, KH, NCB, PF, 32, 4, 4>(a, st);
+      if (v == 1) return launch_fused_pc<W, KH, NCB, PF, 32, 4, 4, true>(a, st);
       if (v == 2) return launch_fused_pc<W, KH, NCB, PF, 64, 8, 4>(a, st);
       if (v == 4) return launch_fused_pc<W, KH, NCB, PF, 64, 2, 4>(a, st);
       if (v == 5) return launch_fused_pc<W, KH, NCB, PF, 64, 6, 4>(a, st);
     }
-    if (v == 3) return launch_fused_pc<W, KH, NCB, PF, 64, 4, 4>(a, st);
     if constexpr (KH == 1) {
-      // With a self term (GIN's (1 + eps) x) the producers first load the tile's own rows and a third barrier separates
-      // that from the runs: the 64-row kernel loses its edge (24.1 / 26.1 ms, out only / aggregated rows kept, against
-      // 23.75 / 25.3 for 32-row tiles and 23.8 / 24.9 for the one-role kernel; profiles/r03_fused_variants.json)
-      if (a.S != nullptr && v == 0 && a.dout <= 256)
-        return a.P != nullptr ? launch_fused_tiles<W, KH, NCB, PF>(a, st) : launch_fused_pc<W, KH, NCB, PF, 32, 4, 4>(a, st);
+      if (v == 3) return launch_fused_pc<W, KH, 1, PF, 64, 4, 4, true>(a, st);
+      if (a.dout > 256 && a.S != nullptr) return launch_fused_tiles<W, KH, NCB, PF>(a, st);   // (no self-term form with 8 consumers)
       if (a.dout > 256) return launch_fused_pc<W, KH, 1, PF, 64, 4, 8>(a, st);   // one column block per consumer wave
-      return launch_fused_pc<W, KH, 1, PF, 64, 4, 4>(a, st);
+      return launch_fused_pc<W, KH, 1, PF, 64, 4, 4, true>(a, st);
     } else {
       // F = 512: the accumulators of both column blocks live across the K halves (8 consumers with one block each
       // need 12 waves of <= 168 registers and spill); the two blocks walk K together instead
-      if (a.dout == 512) return launch_fused_pc<W, KH, 2, PF, 64, 4, 4>(a, st);
+      if (a.dout == 512) return launch_fused_pc<W, KH, 2, PF, 64, 4, 4, true>(a, st);
       if (a.dout > 256) return launch_fused_tiles<W, KH, NCB, PF>(a, st);   // (a ragged second block: the one-role kernel)
-      return launch_fused_pc<W, KH, 1, PF, 64, 4, 4>(a, st);
+      return launch_fused_pc<W, KH, 1, PF, 64, 4, 4, true>(a, st);
     }
   } else {
-    return launch_fused_pc<W, KH, NCB, PF, 32, 4, 4>(a, st);
+    return launch_fused_pc<W, KH, NCB, PF, 32, 4, 4, true>(a, st);
   }
 }
 
