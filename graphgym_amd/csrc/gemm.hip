@@ -536,7 +536,9 @@ __global__ __launch_bounds__(kBlock, 2) void dense_wgrad_wide_kernel(const float
 constexpr int WPC_MFMA_WAVES = 8, WPC_LOAD_WAVES = 4;
 constexpr int WPC_THREADS = 64 * (WPC_MFMA_WAVES + WPC_LOAD_WAVES);
 
-template <bool RELU>
+// DT: 128-column halves of d (2: d <= 256, wave w owns f rows 64 (w >> 1) .. and d half w & 1; 1: d <= 128, wave w owns f
+// rows 32 w .. and all of d — 64 accumulator registers)
+template <bool RELU, int DT>
 __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const float* __restrict__ P, int64_t ldp,
                                                                         const float* G, int64_t ldg,
                                                                         const float* __restrict__ Y, int64_t ldy,
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
                                                                         float* __restrict__ slabs,
                                                                         float* __restrict__ bias_slabs) {
   __shared__ __attribute__((aligned(16))) unsigned char Pimg[2][3][2][kPlaneBytes];   // [stage][plane][128-column half]
-  __shared__ __attribute__((aligned(16))) unsigned char Gimg[2][3][2][kPlaneBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char Gimg[2][3][DT][kPlaneBytes];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t c = blockIdx.x;
@@ -587,13 +589,15 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
         const float* ps = P + m * ldp + pcol[h];
         rp[s][h][0] = *reinterpret_cast<const f32x4*>(ps);
         rp[s][h][1] = *reinterpret_cast<const f32x4*>(ps + 4);
-        const float* gs = G + m * ldg + gcol[h];
-        rg[s][h][0] = *reinterpret_cast<const f32x4*>(gs);
-        rg[s][h][1] = *reinterpret_cast<const f32x4*>(gs + 4);
-        if constexpr (RELU) {
-          const float* ys = Y + m * ldy + gcol[h];
-          ry[s][h][0] = *reinterpret_cast<const f32x4*>(ys);
-          ry[s][h][1] = *reinterpret_cast<const f32x4*>(ys + 4);
+        if (h < DT) {                                  // (compile-time after unrolling)
+          const float* gs = G + m * ldg + gcol[h];
+          rg[s][h][0] = *reinterpret_cast<const f32x4*>(gs);
+          rg[s][h][1] = *reinterpret_cast<const f32x4*>(gs + 4);
+          if constexpr (RELU) {
+            const float* ys = Y + m * ldy + gcol[h];
+            ry[s][h][0] = *reinterpret_cast<const f32x4*>(ys);
+            ry[s][h][1] = *reinterpret_cast<const f32x4*>(ys + 4);
+          }
         }
       }
     };
@@ -603,31 +607,35 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
       const bool ok = m < me;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        float pv[8], gv[8];
+        float pv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          pv[i] = (ok && pin[h]) ? rp[s][h][i >> 2][i & 3] : 0.f;
-          gv[i] = (ok && gin[h]) ? rg[s][h][i >> 2][i & 3] : 0.f;
-          if constexpr (RELU) gv[i] = ry[s][h][i >> 2][i & 3] > 0.f ? gv[i] : 0.f;
-        }
-        if constexpr (RELU) {
-          if (GM != nullptr && ok && gin[h]) {
-            float* go = GM + m * ldgm + gcol[h];
-            *reinterpret_cast<f32x4*>(go) = f32x4{gv[0], gv[1], gv[2], gv[3]};
-            *reinterpret_cast<f32x4*>(go + 4) = f32x4{gv[4], gv[5], gv[6], gv[7]};
-          }
-        }
+        for (int i = 0; i < 8; ++i) pv[i] = (ok && pin[h]) ? rp[s][h][i >> 2][i & 3] : 0.f;
         bf16x8 sp[3];
         split3_bf16(pv, sp[0], sp[1], sp[2]);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(&Pimg[buf][pl][h][off]) = sp[pl];
-        bf16x8 sg[3];
-        split3_bf16(gv, sg[0], sg[1], sg[2]);
+        if (h < DT) {
+          float gv[8];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(&Gimg[buf][pl][h][off]) = sg[pl];
-        if (do_bias) {
+          for (int i = 0; i < 8; ++i) {
+            gv[i] = (ok && gin[h]) ? rg[s][h][i >> 2][i & 3] : 0.f;
+            if constexpr (RELU) gv[i] = ry[s][h][i >> 2][i & 3] > 0.f ? gv[i] : 0.f;
+          }
+          if constexpr (RELU) {
+            if (GM != nullptr && ok && gin[h]) {
+              float* go = GM + m * ldgm + gcol[h];
+              *reinterpret_cast<f32x4*>(go) = f32x4{gv[0], gv[1], gv[2], gv[3]};
+              *reinterpret_cast<f32x4*>(go + 4) = f32x4{gv[4], gv[5], gv[6], gv[7]};
+            }
+          }
+          bf16x8 sg[3];
+          split3_bf16(gv, sg[0], sg[1], sg[2]);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) bs[h][i] += gv[i];
+          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(&Gimg[buf][pl][h][off]) = sg[pl];
+          if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bs[h][i] += gv[i];
+          }
         }
       }
     };
@@ -655,7 +663,7 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
     if (do_bias) {   // 16 threads hold partial sums of the same 8 columns: add them in row order through LDS
       float (*red)[256] = reinterpret_cast<float (*)[256]>(&Pimg[0][0][0][0]);      // [16][256] floats = 16 KiB
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < DT; ++h) {
         *reinterpret_cast<f32x4*>(&red[l_row][128 * h + l_col]) = f32x4{bs[h][0], bs[h][1], bs[h][2], bs[h][3]};
         *reinterpret_cast<f32x4*>(&red[l_row][128 * h + l_col + 4]) = f32x4{bs[h][4], bs[h][5], bs[h][6], bs[h][7]};
       }
@@ -670,11 +678,14 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
     }
   } else {
     // ------------------------------------------------ MFMA waves ------------------------------------------------
-    const int wf = wave >> 1, wd = wave & 1;
+    constexpr int NI = DT;                  // 32-row f blocks per wave
+    const int wf = DT == 2 ? wave >> 1 : wave;                 // f block of 64 (DT == 2) / 32 (DT == 1) rows
+    const int wd = DT == 2 ? wave & 1 : 0;
+    const int f_lo = DT == 2 ? wf * 64 : wf * 32;              // first f row of this wave
     const int fr = lane & 31, fk = lane >> 5;
-    f32x16 acc[2][4];
+    f32x16 acc[NI][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -683,10 +694,10 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
     for (int64_t t = 0; t < nsteps; ++t) {
       const int buf = (int)(t & 1);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NI; ++i) {
         bf16x8 as[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) as[pl] = tr_read8(Pimg[buf][pl][wf >> 1], (wf & 1) * 64 + i * 32, lane);
+        for (int pl = 0; pl < 3; ++pl) as[pl] = tr_read8(Pimg[buf][pl][f_lo >> 7], (f_lo & 127) + i * 32, lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           bf16x8 b3[3];
@@ -710,10 +721,10 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
     for (int j = 0; j < 4; ++j) {
       const int col = wd * 128 + j * 32 + fr;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = wf * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+          const int row = f_lo + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
           if (row < F && col < d) slab[(int64_t)row * d + col] = acc[i][j][r];
         }
       }
@@ -1086,16 +1097,16 @@ static int wgrad_common(const float* P, int64_t ldp, const float* G, int64_t ldg
     }
     return MP_OK;
   }
-  if (vec && F > 128 && F <= 256 && d > 128 && d <= 256 && F % 8 == 0 && d % 8 == 0 && !wgrad_no_pc()) {   // loaders + MFMA waves, the whole gradient per workgroup
+  if (vec && F > 128 && F <= 256 && d >= 64 && d <= 256 && F % 8 == 0 && d % 8 == 0 && !wgrad_no_pc()) {   // loaders + MFMA waves, the whole gradient per workgroup
     const int64_t pc_chunk = wgrad_pc_chunk(M);
     const int64_t n_pc = ceil_div(M, pc_chunk);            // <= n_chunk: the workspace of mp_dense_wgrad_ws_bytes holds it
     float* pc_bias = dbias ? (float*)ws + (size_t)n_pc * F * d : nullptr;
-    if (Y)
-      hipLaunchKernelGGL(dense_wgrad_pc_kernel<true>, dim3((unsigned)n_pc), dim3(WPC_THREADS), 0, st, P, ldp, G, ldg, Y,
-                         ldy, GM, ldgm, M, F, d, pc_chunk, (float*)ws, pc_bias);
-    else
-      hipLaunchKernelGGL(dense_wgrad_pc_kernel<false>, dim3((unsigned)n_pc), dim3(WPC_THREADS), 0, st, P, ldp, G, ldg, Y,
-                         ldy, GM, ldgm, M, F, d, pc_chunk, (float*)ws, pc_bias);
+#define MP_WPC(RELUV, DTV)                                                                                          \
+  hipLaunchKernelGGL((dense_wgrad_pc_kernel<RELUV, DTV>), dim3((unsigned)n_pc), dim3(WPC_THREADS), 0, st, P, ldp, G, \
+                     ldg, Y, ldy, GM, ldgm, M, F, d, pc_chunk, (float*)ws, pc_bias)
+    if (d > 128) { if (Y) MP_WPC(true, 2); else MP_WPC(false, 2); }
+    else { if (Y) MP_WPC(true, 1); else MP_WPC(false, 1); }
+#undef MP_WPC
     MP_LAUNCH_CHECK();
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(flat_grid((int64_t)F * d * 16)), dim3(kBlock), 0, st, (const float*)ws,
                        n_pc, (int64_t)F * d, dW);
