@@ -100,6 +100,19 @@ t = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True, out=y))
 rec("agg_dense (aggregate -> transform, one kernel; bf16x3 product)", t, agg_bytes, tflop=2.0 * n * d * d / 1e12, note="moves the aggregation's bytes AND does the transform's flops (fp32-accurate three-way bf16 split on the bf16 matrix pipe)")
 t = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True, out=y, bf16x3=False))
 rec("agg_dense, exact-f32 MFMA product (round 1's form)", t, agg_bytes, tflop=2.0 * n * d * d / 1e12)
+t = timeit(lambda: ops._raw_agg_dense(g, x, W, b, True, out=y, S=x, self_scale=1.0))
+rec("agg_dense with a self term (GIN's (1 + eps) x + sum, then the first Dense)", t, agg_bytes + n * d * 4 / 1e9, tflop=2.0 * n * d * d / 1e12)
+if os.environ.get("KT_F512", "1") == "1":     # config C5's width: two K halves over the row tile
+    x5 = torch.empty((n, 512), device=dev).uniform_(-1, 1)
+    y5 = placement.empty_or_torch((n, 512), dev, reads=(x5,))
+    W5 = torch.randn(512, 512, device=dev) * 0.03
+    b5 = torch.randn(512, device=dev)
+    t = timeit(lambda: ops._raw_agg_dense(g, x5, W5, b5, True, out=y5))
+    rec("agg_dense F = 512 -> 512 (two K halves per 64-row tile, both column blocks walk K together)", t,
+        (nnz * (512 * 4 + 8) + n * (512 * 4 + 4)) / 1e9, tflop=2.0 * n * 512 * 512 / 1e12,
+        note="index / value streams are read once per K half")
+    del x5, y5, W5, b5
+    torch.cuda.empty_cache()
 # the ID layer: act(A (x W + S x W_id) + b), 1 % identity nodes
 Wid = torch.randn(d, d, device=dev) * 0.05
 with torch.no_grad():
