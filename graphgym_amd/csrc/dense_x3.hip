@@ -271,6 +271,196 @@ __global__ __launch_bounds__(X3_THREADS, 1) void dense_x3_kernel(const float* __
   }
 }
 
+// The same transform with loading and multiplying on DIFFERENT waves (round 3, d = 256).  In the kernel above every wave
+// issues its share of the LDS-DMA pieces, and a vector memory instruction holds its wave at issue (~50 cycles per 1 KiB
+// piece with every wave issuing) while that wave issues no MFMAs: the MFMAs alone take 4.0 ms, the memory side alone
+// 3.9 ms, together 7.0-7.7.  Here a workgroup is 12 waves: waves 0-7 keep the row tiling (wave w: rows 32 w .. + 31, all
+// d columns), read fragments, split, multiply and — once per row block — store their tiles; waves 8-11 do nothing but
+// request the W slice of the next step and, every other step, the P stage after the current one, wait for them with
+// counted vmcnt, and meet the others at the one barrier per 16-k step.  12 waves mean 168 registers: the MFMA waves
+// keep ONE fragment of P (the split of step n + 1 is not computed under the MFMAs of step n; the SIMD's other MFMA
+// wave covers the gap).  7.68 -> 7.14 ms at 10^7 x 256 x 256, 14.2 -> 13.0 ms at F = 512 (in-process order A/B,
+// scripts/bench_dense_x3.py with MP_X3_PC=0 / 1).  Tried on top and dropped: W slices requested TWO steps ahead through a
+// three-slot ring, paid for with half-tile output images (158 KB of LDS): 7.65 vs 7.92 ms for the one-role kernel on
+// its box — no better; a W slice landing within its step was not the limit.
+#ifndef MP_X3PC_ABL
+#define MP_X3PC_ABL 0   // ablation bits (timing studies, wrong results): 1 loaders idle after the prologue, 2 no MFMAs, 4 no output
+#endif
+constexpr int X3PC_LOADERS = 4;
+constexpr int X3PC_THREADS = 64 * (X3_WAVES + X3PC_LOADERS);
+
+__global__ __launch_bounds__(X3PC_THREADS, 3) void dense_x3_pc_kernel(const float* __restrict__ P, int64_t ldp,
+                                                                      const unsigned char* __restrict__ Ws,
+                                                                      const float* __restrict__ bias, int act,
+                                                                      float* __restrict__ out, int64_t ldo, int64_t M,
+                                                                      int32_t F) {
+  constexpr int NCB = 8;
+  constexpr int d = 32 * NCB;
+  constexpr int BSTAGE = 96 * d;             // [3 planes][2 k-chunks of 8][d columns][8 bf16]
+  constexpr int BPIECES = 3 * NCB;           // 1 KiB pieces of one W stage
+  constexpr int QP = NCB / 2;                // pieces per (plane, k-chunk)
+  // ONE shared array (see dense_x3_kernel)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * X3_ASTAGE + 2 * BSTAGE + X3_WAVES * X3_OSTAGE + 4 * d];
+  unsigned char* const Abuf = lds;
+  unsigned char* const Bbuf = lds + 2 * X3_ASTAGE;
+
+  const int tid = threadIdx.x, lane_c = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = F >> 4;                      // 16-k steps per row block (even: F % 32 == 0)
+  const int T = F >> 5;                      // 32-k stages of P per row block (>= 2)
+  const int64_t nrb = (M + X3_BM - 1) / X3_BM;
+  if ((int64_t)blockIdx.x >= nrb) return;
+  const int nloc = (int)((nrb - blockIdx.x + gridDim.x - 1) / gridDim.x);   // row blocks of this workgroup
+  const int nsteps = nloc * S;
+  const int nstages = nloc * T;
+  const uint32_t ldp_b = (uint32_t)ldp * 4u, ldo_b = (uint32_t)ldo * 4u;
+
+  if (wave >= X3_WAVES) {
+    // ------------------------------------------------ loaders ------------------------------------------------
+    const int lw = wave - X3_WAVES;
+    // piece i (8 rows x 128 B) of the 32 rows of MFMA wave rw, P stage `stage` of row-block iteration `it` (layout and
+    // swizzle: dense_x3_kernel's issue_A)
+    auto issue_A = [&](int it, int stage, int buf, int rw, int i) {
+      int lane = lane_c;
+      asm volatile("" : "+v"(lane));
+      const int p_row = lane >> 3;
+      const int64_t r0 = ((int64_t)blockIdx.x + (int64_t)it * gridDim.x) * X3_BM;
+      const int64_t left = M - r0;
+      const int row = 32 * rw + 8 * i + p_row;
+      const int gch = (lane & 7) ^ ((row >> 1) & 7);
+      const int srow = row < left ? row : (int)left - 1;
+      const unsigned char* base = reinterpret_cast<const unsigned char*>(P) + r0 * (int64_t)ldp_b;
+      glds16(base + ((uint32_t)srow * ldp_b + (uint32_t)(128 * stage + 16 * gch)),
+             Abuf + buf * X3_ASTAGE + (32 * rw + 8 * i) * 128);
+    };
+    auto issue_stage = [&](int m) {          // global stage m = (row-block iteration m / T, stage m % T) -> slot m & 1
+      const int it = m / T, st = m - it * T;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_A(it, st, m & 1, 2 * lw + r, i);
+    };
+    auto issue_B = [&](int s, int buf) {     // W slice s (k = 16 s .. + 15): loader lw moves pieces lw, lw + 4, ...
+      int lane = lane_c;
+      asm volatile("" : "+v"(lane));
+#pragma unroll
+      for (int j = 0; j < BPIECES / X3PC_LOADERS; ++j) {
+        const int p = lw + X3PC_LOADERS * j;
+        const int ph = p / QP, q = p % QP;
+        const size_t src = (size_t)(ph >> 1) * ((size_t)F * d * 2) + (size_t)(2 * s + (ph & 1)) * (d * 16) + q * 1024;
+        glds16(Ws + src + lane * 16, Bbuf + buf * BSTAGE + p * 1024);
+      }
+    };
+    issue_B(0, 0);
+    issue_stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int s = 0;
+    for (int n = 0; n < nsteps; ++n) {
+      const int s1 = s + 1 == S ? 0 : s + 1;
+      // W slice of step n + 1: its buffer was last read in step n - 1, which every wave has left.  P stage (n >> 1) + 1
+      // at even n: its slot held the stage whose second half was read in step n - 1; it is first read in step n + 2.
+      const bool more_w = n + 1 < nsteps && !(MP_X3PC_ABL & 1);
+      const bool more_p = !(n & 1) && (n >> 1) + 1 < nstages && !(MP_X3PC_ABL & 1);
+      if (more_w) issue_B(s1, (n + 1) & 1);
+      if (more_p) {
+        issue_stage((n >> 1) + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // the W slice has landed; the 8 pieces of P stay in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      s = s1;
+    }
+    return;
+  }
+
+  // ------------------------------------------------ MFMA waves ------------------------------------------------
+  auto read_split = [&](int n, bf16x8 (&p3)[3]) {
+    int lane = lane_c;
+    asm volatile("" : "+v"(lane));
+    const int f_row = 32 * wave + (lane & 31), f_h = lane >> 5, f_sw = (f_row >> 1) & 7;
+    const unsigned char* A = Abuf + ((n >> 1) & 1) * X3_ASTAGE + f_row * 128;
+    const int g0 = 4 * (n & 1) + 2 * f_h;
+    const x3_f32x4 x0 = *reinterpret_cast<const x3_f32x4*>(A + 16 * (g0 ^ f_sw));
+    const x3_f32x4 x1 = *reinterpret_cast<const x3_f32x4*>(A + 16 * ((g0 + 1) ^ f_sw));
+    const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    split3_bf16(xv, p3[0], p3[1], p3[2]);
+  };
+  f32x16 acc[NCB];
+  unsigned char* const Obuf = lds + 2 * X3_ASTAGE + 2 * BSTAGE + wave * X3_OSTAGE;
+  float* const bias_l = reinterpret_cast<float*>(lds + 2 * X3_ASTAGE + 2 * BSTAGE + X3_WAVES * X3_OSTAGE);
+  if (tid < d) bias_l[tid] = bias != nullptr ? bias[tid] : 0.f;
+  auto flush_tile = [&](int it, int cb) {    // (dense_x3_kernel's epilogue: a 32 x 32 tile through the wave's LDS image)
+    if ((MP_X3PC_ABL & 4) && act != 77) return;
+    int lane = lane_c;
+    asm volatile("" : "+v"(lane));
+    const int f_h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const x3_f32x4 b4 = *reinterpret_cast<const x3_f32x4*>(bias_l + cb * 32 + 8 * q + 4 * f_h);
+      x3_f32x4 v = {acc[cb][4 * q] + b4[0], acc[cb][4 * q + 1] + b4[1], acc[cb][4 * q + 2] + b4[2],
+                    acc[cb][4 * q + 3] + b4[3]};
+      if (act == MP_ACT_RELU) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      }
+      *reinterpret_cast<x3_f32x4*>(Obuf + (lane & 31) * X3_OROW + (8 * q + 4 * f_h) * 4) = v;
+    }
+    const int64_t r0 = ((int64_t)blockIdx.x + (int64_t)it * gridDim.x) * X3_BM + 32 * wave;
+    const int64_t left = M - r0;
+    const int nrow = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
+    unsigned char* const base = reinterpret_cast<unsigned char*>(out) + r0 * (int64_t)ldo_b + cb * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const x3_f32x4 v = *reinterpret_cast<const x3_f32x4*>(Obuf + (8 * i + (lane >> 3)) * X3_OROW + 16 * (lane & 7));
+      if (8 * i + (lane >> 3) < nrow)
+        *reinterpret_cast<x3_f32x4*>(base + ((uint32_t)(8 * i + (lane >> 3)) * ldo_b + (uint32_t)(16 * (lane & 7)))) = v;
+    }
+  };
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // bias_l is written
+  __builtin_amdgcn_s_barrier();              // W slice 0 and P stage 0 have landed
+  int s = 0, cur_it = 0;
+  for (int n = 0; n < nsteps; ++n) {
+    if (s == 0 && n > 0) {                   // seam: the previous row block's tiles, then restart the accumulators
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        flush_tile(cur_it, cb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+      }
+      ++cur_it;
+    }
+    bf16x8 p3[3];
+    read_split(n, p3);
+    {
+      int lane = lane_c;
+      asm volatile("" : "+v"(lane));
+      const unsigned char* B = Bbuf + (n & 1) * BSTAGE + (lane >> 5) * (d * 16) + (lane & 31) * 16;
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {
+        bf16x8 w3[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          w3[pl] = *reinterpret_cast<const bf16x8*>(B + pl * (2 * d * 16) + c * 512);
+#if MP_X3PC_ABL & 2
+        asm volatile("" ::"v"(w3[0]), "v"(w3[1]), "v"(w3[2]), "v"(p3[0]), "v"(p3[1]), "v"(p3[2]));
+#else
+        mfma6(acc[c], w3, p3);
+#endif
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this step's LDS reads are done before the loaders overwrite
+    __builtin_amdgcn_s_barrier();
+    s = s + 1 == S ? 0 : s + 1;
+  }
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) flush_tile(cur_it, cb);
+}
+
 // W [K rows, n columns] (trans == 0: B[k][c] = W[k][c], K = F, n = d) or its transpose (trans != 0: B[k][c] = W[c][k],
 // W [n rows, K columns]) -> [3][K / 8][n][8] bf16, plane s = bf16(B - sum of the planes before it)
 __global__ __launch_bounds__(kBlock) void split_w_kernel(const float* __restrict__ W, int64_t ldw, int32_t K,
@@ -323,7 +513,12 @@ int mp_dense_x3_f32(const float* P, int64_t ldp, const void* W_split, const floa
   switch (d) {
     case 64: hipLaunchKernelGGL(dense_x3_kernel<2>, grid, block, 0, st, P, ldp, Ws, bias, (int)act, out, ldo, M, F); break;
     case 128: hipLaunchKernelGGL(dense_x3_kernel<4>, grid, block, 0, st, P, ldp, Ws, bias, (int)act, out, ldo, M, F); break;
-    default: hipLaunchKernelGGL(dense_x3_kernel<8>, grid, block, 0, st, P, ldp, Ws, bias, (int)act, out, ldo, M, F); break;
+    default: {
+      const char* e = getenv("MP_X3_PC");                    // MP_X3_PC=0: the one-role kernel (A/B studies), read per call
+      if (e && e[0] == '0') hipLaunchKernelGGL(dense_x3_kernel<8>, grid, block, 0, st, P, ldp, Ws, bias, (int)act, out, ldo, M, F);
+      else hipLaunchKernelGGL(dense_x3_pc_kernel, grid, dim3(X3PC_THREADS), 0, st, P, ldp, Ws, bias, (int)act, out, ldo, M, F);
+      break;
+    }
   }
   MP_LAUNCH_CHECK();
   return MP_OK;
