@@ -550,7 +550,12 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
   __shared__ __attribute__((aligned(16))) unsigned char Gimg[2][3][DT][kPlaneBytes];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t c = blockIdx.x;
+  // wider gradients: output tiles of 256 (f) x 128 DT (d), tile index fastest (P is then read once per d tile, g once
+  // per f tile: F = d = 512 moves each operand twice)
+  const int tf = (F + 255) / 256, td = (d + 128 * DT - 1) / (128 * DT);
+  const int tile = (int)(blockIdx.x % (unsigned)(tf * td));
+  const int64_t c = blockIdx.x / (unsigned)(tf * td);
+  const int f0 = (tile / td) * 256, d0 = (tile % td) * 128 * DT;
   const int64_t mb = c * chunk;
   const int64_t me = mb + chunk < M ? mb + chunk : M;
   const int64_t ntiles = (me - mb + BK - 1) / BK;      // >= 1: the host launches ceil(M / chunk) workgroups
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
     const int lt = tid - 64 * WPC_MFMA_WAVES;
     const int l_row = lt >> 4;               // 0..15: node row inside the tile
     const int l_col = (lt & 15) * 8;         // 8 consecutive columns of each 128-column half
-    const bool do_bias = bias_slabs != nullptr;
+    const bool do_bias = bias_slabs != nullptr && f0 == 0;
     float bs[2][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -577,8 +582,8 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int fc = 128 * h + l_col;
-      pin[h] = fc < F; gin[h] = fc < d;
-      pcol[h] = pin[h] ? fc : 0; gcol[h] = gin[h] ? fc : 0;
+      pin[h] = f0 + fc < F; gin[h] = d0 + fc < d;
+      pcol[h] = pin[h] ? f0 + fc : 0; gcol[h] = gin[h] ? d0 + fc : 0;
     }
     f32x4 rp[NSET][2][2], rg[NSET][2][2], ry[RELU ? NSET : 1][2][2];
     auto fetch = [&](int s, int64_t tile) {            // s: compile-time after unrolling
@@ -622,7 +627,7 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
             if constexpr (RELU) gv[i] = ry[s][h][i >> 2][i & 3] > 0.f ? gv[i] : 0.f;
           }
           if constexpr (RELU) {
-            if (GM != nullptr && ok && gin[h]) {
+            if (GM != nullptr && f0 == 0 && ok && gin[h]) {
               float* go = GM + m * ldgm + gcol[h];
               *reinterpret_cast<f32x4*>(go) = f32x4{gv[0], gv[1], gv[2], gv[3]};
               *reinterpret_cast<f32x4*>(go + 4) = f32x4{gv[4], gv[5], gv[6], gv[7]};
@@ -669,12 +674,12 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
       }
     }
     __syncthreads();                                   // (the MFMA waves pass it on their way to the slab stores)
-    if (do_bias && lt < 256 && lt < d) {
+    if (do_bias && lt < 128 * DT && d0 + lt < d) {
       const float (*red)[256] = reinterpret_cast<const float (*)[256]>(&Pimg[0][0][0][0]);
       float sacc = 0.f;
 #pragma unroll
       for (int r = 0; r < BK; ++r) sacc += red[r][lt];
-      bias_slabs[c * (int64_t)d + lt] = sacc;
+      bias_slabs[c * (int64_t)d + d0 + lt] = sacc;
     }
   } else {
     // ------------------------------------------------ MFMA waves ------------------------------------------------
@@ -719,12 +724,12 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
     float* slab = slabs + c * (int64_t)F * d;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int col = wd * 128 + j * 32 + fr;
+      const int col = d0 + wd * 128 + j * 32 + fr;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = f_lo + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+          const int row = f0 + f_lo + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
           if (row < F && col < d) slab[(int64_t)row * d + col] = acc[i][j][r];
         }
       }
@@ -1097,12 +1102,14 @@ static int wgrad_common(const float* P, int64_t ldp, const float* G, int64_t ldg
     }
     return MP_OK;
   }
-  if (vec && F > 128 && F <= 256 && d >= 64 && d <= 256 && F % 8 == 0 && d % 8 == 0 && !wgrad_no_pc()) {   // loaders + MFMA waves, the whole gradient per workgroup
+  if (vec && F > 128 && d >= 64 && F % 8 == 0 && d % 8 == 0 && !wgrad_no_pc()) {   // loaders + MFMA waves, the whole gradient per workgroup
     const int64_t pc_chunk = wgrad_pc_chunk(M);
     const int64_t n_pc = ceil_div(M, pc_chunk);            // <= n_chunk: the workspace of mp_dense_wgrad_ws_bytes holds it
     float* pc_bias = dbias ? (float*)ws + (size_t)n_pc * F * d : nullptr;
+    const int64_t pc_tiles = ceil_div(F, 256) * ceil_div(d, d > 128 ? 256 : 128);
+    if (n_pc * pc_tiles >= INT32_MAX) return MP_ERR_UNSUPPORTED;
 #define MP_WPC(RELUV, DTV)                                                                                          \
-  hipLaunchKernelGGL((dense_wgrad_pc_kernel<RELUV, DTV>), dim3((unsigned)n_pc), dim3(WPC_THREADS), 0, st, P, ldp, G, \
+  hipLaunchKernelGGL((dense_wgrad_pc_kernel<RELUV, DTV>), dim3((unsigned)(n_pc * pc_tiles)), dim3(WPC_THREADS), 0, st, P, ldp, G, \
                      ldg, Y, ldy, GM, ldgm, M, F, d, pc_chunk, (float*)ws, pc_bias)
     if (d > 128) { if (Y) MP_WPC(true, 2); else MP_WPC(false, 2); }
     else { if (Y) MP_WPC(true, 1); else MP_WPC(false, 1); }

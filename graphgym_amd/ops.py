@@ -169,7 +169,9 @@ def agg_dense_supported(g, x, W):
             and g.nnz > 0 and g.max_row_entries() <= FUSED_MAX_ROW)
 
 
-BF16X3_MIN_ROWS = 1 << 19   # below this the split of W (one small launch per call) costs more than the shorter MFMA phase saves
+BF16X3_MIN_ROWS = 1 << 14   # below this the split of W (one ~5 us launch per call) costs more than the shorter MFMA phase saves
+                            # (round 2: 2^19, set on the one-role kernel; an ego batch of 1.5 * 10^5 rows at F = 512 ran the
+                            # exact-f32 product at 1.24 ms per layer, MFMA-bound)
 
 
 def _split_bf16_t(W):

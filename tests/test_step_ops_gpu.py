@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("M,Fi,d", [(1000, 256, 256), (777, 264, 132), (500, 1433, 128), (333, 1, 7), (70000, 128, 64),
-                                    (129, 8, 260)])
+                                    (129, 8, 260),
+                                    # the loader / MFMA-wave kernel: one tile, d <= 128, several f and d tiles with ragged
+                                    # edges, more rows than one workgroup's range, a range that ends inside a 16-row tile
+                                    (9001, 256, 128), (3000, 512, 512), (2500, 520, 264), (1100000, 136, 72), (4097, 200, 256)])
 def test_wgrad_with_relu_mask(dev, M, Fi, d):
     from graphgym_amd import ops
     g = torch.Generator().manual_seed(M + d)
