@@ -637,31 +637,29 @@ __device__ __forceinline__ void mfma_rows(const float (*T)[FH + 4], const float*
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same layer with the two phases on DIFFERENT waves (round 3).  Measured on the kernel above
-// (profiles/r03_fused_phases.json): a workgroup gathers only 60 % of its time — phase B is 24 % (its W fragments are L2
-// hits, but the vector memory path returns in order, so behind the gathers of the CU's other waves each of the 16
-// fetch rounds costs ~1 us), the head of the tile and the output store 6 % each — and with four workgroups per CU
-// there are moments when too few of them gather.  Here a workgroup is 8 waves walking tiles it draws from a counter:
-//   waves 0-3 (producers): initialise tile buffer b, gather their runs into it, add the carries        — item j
-//   waves 4-7 (consumers): store the aggregated rows, multiply buffer b^1 by W, store the output       — item j - 1
-// An item is one K half of one tile; the two roles meet at three workgroup barriers per item (tile initialised /
-// runs reduced / carries added), and the consumers reach each of them long before the producers, so the gathers of a
-// workgroup never stop for a product or a store.  Two buffers: 2 x 33 KiB of LDS, two workgroups (16 waves) per CU,
-// 8 of them gathering all the time — the plan-based kernel runs at full speed with 8 waves per CU
-// (profiles/r03_occupancy_sweep.jsonl).  Tiles come from an atomic counter in ascending order, so the hub tiles at the
-// head of the matrix start first and a workgroup that holds one simply draws fewer tiles; which workgroup computes a
-// tile does not enter its arithmetic: same bits as the kernel above.
+// The same layer with the two phases on DIFFERENT waves (round 3; DESIGN.md §4.5 "Round 3").  Measured on the kernel
+// above (profiles/r03_fused_phases.json): a workgroup gathers only 60 % of its time — phase B is 24 % (its W fragments
+// are L2 hits, but the vector memory path returns in order, so behind the gathers of the CU's other waves each of the 16
+// fetch rounds costs ~1 us), the head of the tile and the output store 6 % each.  Here a workgroup is NP + NC waves
+// walking tiles it draws from a counter, over TWO tile buffers in LDS:
+//   waves 0 .. NP-1 (producers): gather their runs of item j into buffer b, add the carries
+//   the NC other waves (consumers): store the aggregated rows of item j - 1, multiply buffer b ^ 1 by W, store the output
+// An item is one K half of one tile of TR rows.  The roles run SEPARATE loops over the same item sequence and meet at two
+// workgroup barriers per item (runs reduced / carries added); the consumers usually reach them first, so the gathers of
+// a workgroup do not stop for a product or a store.  Tiles come from an atomic counter in ascending order: the hub tiles
+// at the head of the matrix start first and a workgroup that holds one simply draws fewer tiles; which workgroup computes
+// a tile does not enter its arithmetic (same bits every run; against the kernel above only rows cut by a run boundary
+// differ, the cut positions depend on TR and NP).
 //
-// TR rows per tile, NP producer waves (the consumers are always four: 64 output columns each).  Every tile reads ALL of
-// W from L2 — 6 bytes per weight in the three-way bf16 split, 393 KB at F = dout = 256, more than the tile's own
-// gathers (352 KB) — and that traffic is what the product costs: with W served from L1 the layer runs at 20.0 ms,
-// below the plain aggregation (in-process ablations, profiles/r03_fused_ablation.json: 22.3 ms as is, 21.2 ms with one of
-// the three planes not read, 19.7 ms without the product, 17.6 ms without product and store).  A tile of TR = 64 rows
-// uses every W fragment for two 32-row MFMA blocks: half the traffic.  Its two buffers take 133 KB of LDS — one
-// workgroup per CU — so the workgroup brings its own 8 gathering waves (NP = 8: 12 waves, 168 registers each).
-// NC consumer waves, 64 output columns each: 4 for dout <= 256; 8 for wider outputs, where four consumers — two column
-// blocks each, a W fragment round trip of ~1 us per K group and block behind the CU's gathers — take longer than the
-// producers need for the next tile and the layer becomes consumer-bound (F = dout = 512: 53.2 ms with 4, XX with 8).
+// Shapes (dispatch: launch_fused below).  Every tile reads ALL of W from L2 — 6 bytes per weight in the three-way bf16
+// split, 393 KB at F = dout = 256, more than a 32-row tile's own gathers (352 KB) — and that traffic is what the
+// product costs: with W served from L1 the 32-row form runs at 20.0 ms, below the plain aggregation (ablation builds,
+// profiles/r03_fused_ablation.json: 22.3 ms as is, 21.2 ms with one of the three planes not read, 19.7 ms without the
+// product, 17.6 ms without product and store).  TR = 64 uses every W fragment for two 32-row MFMA blocks: half the
+// traffic; its two buffers take 133 KB of LDS — one workgroup per CU, up to 256 registers per wave.  NP = 4 producers
+// are the optimum there (2: 24.6 ms, 4: 20.97, 6: 21.8, 8: 22.0).  NC = 4 consumers (64 output columns each per block of
+// 256) for dout <= 256; NC = 8 for wider outputs of one K half; F = 512 keeps NC = 4 with both column blocks of a wave
+// walking K together (eight consumers would need 12 waves of <= 168 registers and spill).  HAS_S: the self-term form.
 template <int W, bool WEIGHTED, int U, int KH, int NCB, int PF, bool NT_OUT, bool BF16X3, int TR, int NP, int NC, bool HAS_S>
 __global__ __launch_bounds__((NP + NC) * kWave, TR == 64 ? (NP + NC + 3) / 4 : 4)
 void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32_t n_tiles) {
