@@ -62,6 +62,7 @@ PROTOTYPES = {
                                       _sz, _p]),
     "mp_bn_train_bwd_relu_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _i64, _p, _p, _p,
                                            _sz, _p]),
+    "mp_agg_rows_tiles_f32": (C.c_int, [_p, _p, _p, _i64, C.c_int, _p, _i64, _i32, _p, _i64, C.c_float, _p, _i64, _p]),
     "mp_agg_dense_f32": (C.c_int, [_p, _p, _p, _i64, C.c_int, _p, _i64, _i32, _p, _i64, C.c_float, _p, _i64, _i32, _p, C.c_int,
                                    _p, _p, _i64, _p, _i64, _p, _p]),
     "mp_agg_dense_add_f32": (C.c_int, [_p, _p, _p, _i64, C.c_int, _p, _i64, _i32, _p, _i64, C.c_float, _p, _i64, _i32, _p,

@@ -660,7 +660,10 @@ __device__ __forceinline__ void mfma_rows(const float (*T)[FH + 4], const float*
 // are the optimum there (2: 24.6 ms, 4: 20.97, 6: 21.8, 8: 22.0).  NC = 4 consumers (64 output columns each per block of
 // 256) for dout <= 256; NC = 8 for wider outputs of one K half; F = 512 keeps NC = 4 with both column blocks of a wave
 // walking K together (eight consumers would need 12 waves of <= 168 registers and spill).  HAS_S: the self-term form.
-template <int W, bool WEIGHTED, int U, int KH, int NCB, int PF, bool NT_OUT, bool BF16X3, int TR, int NP, int NC, bool HAS_S>
+// AGG_ONLY: no product — the consumers store the aggregated rows (a.P) and nothing else: the aggregation itself on
+// this kernel's structure (mp_agg_rows_tiles_f32 below).
+template <int W, bool WEIGHTED, int U, int KH, int NCB, int PF, bool NT_OUT, bool BF16X3, int TR, int NP, int NC, bool HAS_S,
+          bool AGG_ONLY = false>
 __global__ __launch_bounds__((NP + NC) * kWave, TR == 64 ? (NP + NC + 3) / 4 : 4)
 void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32_t n_tiles) {
   constexpr int FH = kWave * W;
@@ -675,6 +678,7 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
   __shared__ __attribute__((aligned(16))) float carry[kPcGather - 1][FH];
   __shared__ int carry_row[kPcGather];
   __shared__ float inv_deg[2][kTileRows];
+  __shared__ float deg_l[2][kTileRows];       // mean: the row's entry count (the aggregated rows are DIVIDED by it: exact for equal terms)
   __shared__ int defer_l[2][kTileRows];
   __shared__ int next_tile_s, next2_tile_s;
 
@@ -804,11 +808,13 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
             if (lane == kTileRows - 1) nxt = rp_e;
             if (lane < kTileRows) {
               inv_deg[buf][lane] = (a.mean && nxt > rp_v) ? 1.0f / (float)(nxt - rp_v) : (a.mean ? 0.f : 1.f);
+              deg_l[buf][lane] = (a.mean && nxt > rp_v) ? (float)(nxt - rp_v) : 1.f;
               defer_l[buf][lane] = (a.defer_act != nullptr && R0 + lane < R1) ? (int)a.defer_act[R0 + lane] : 0;
             }
           }
         } else if (wave == 0 && lane < kTileRows) {      // second half: the tile's scales move to this buffer
           inv_deg[buf][lane] = inv_deg[buf ^ 1][lane];
+          deg_l[buf][lane] = deg_l[buf ^ 1][lane];
           defer_l[buf][lane] = defer_l[buf ^ 1][lane];
         }
         if (lane == 0) carry_row[wave] = cont ? first_rl : -1;
@@ -839,13 +845,20 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
           const float* __restrict__ xlane = a.X + k0 + lane * W;
           int rl = first_rl;
           int rend = rp_at(rp_v, rp_e, rl + 1);
-          float accr[W];
+          // Row sums in three levels — the burst's 16 terms (`part`), up to 64 bursts (`accr`), the rest (`tot`) — so that
+          // a wave's share of a hub row (thousands of entries) is not one sequential fp32 chain: with all-ones input the
+          // 10^6-node graph's first row was off by 1.4e-5 of its own value.  A row inside one burst sums as before.
+          float accr[W], part[W], tot[W];
+          int nfold = 0;
 #pragma unroll
-          for (int k = 0; k < W; ++k) accr[k] = 0.f;
+          for (int k = 0; k < W; ++k) { accr[k] = 0.f; part[k] = 0.f; tot[k] = 0.f; }
           // Without a self term nothing initialises the tile: the wave in whose run a row STARTS stores the row (also a
           // row without entries it passes over), later parts of a cut row go to the carries, and the rows no run passes
           // over — empty rows in front of a run's first entry, and behind the tile's last entry — are zeroed by that run.
           auto flush = [&]() {
+#pragma unroll
+            for (int k = 0; k < W; ++k) { accr[k] = tot[k] + (accr[k] + part[k]); part[k] = 0.f; tot[k] = 0.f; }
+            nfold = 0;
             if (cont && rl == first_rl) {
               store_vec<W>(&carry[wave - 1][lane * W], accr);
             } else if (has_s) {
@@ -887,8 +900,15 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
                 }
                 const float w = WEIGHTED ? bcast_f(wvb, jb + j) : 1.f;
 #pragma unroll
-                for (int k = 0; k < W; ++k) accr[k] = fmaf(w, vb[j][k], accr[k]);
+                for (int k = 0; k < W; ++k) part[k] = fmaf(w, vb[j][k], part[k]);
               }
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) { accr[k] += part[k]; part[k] = 0.f; }
+            if (++nfold == 64) {
+#pragma unroll
+              for (int k = 0; k < W; ++k) { tot[k] += accr[k]; accr[k] = 0.f; }
+              nfold = 0;
             }
           };
           int cvb = cvF & 0x7fffffff;   // an identity mark (sign bit) is not part of the index
@@ -978,11 +998,14 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
           const int m = i / VPR, c = (i % VPR) * 4;
           if (PR0 + m < PR1) {
             f32x4 v = *reinterpret_cast<const f32x4*>(&T[pb][m][c]);
-            v *= inv_deg[pb][m];
+            if (a.mean) v /= deg_l[pb][m];     // (not * 1 / count: a mean of equal values must return the value)
             __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.P + (int64_t)(PR0 + m) * a.ldp + pk0 + c));
           }
         }
       }
+      if constexpr (AGG_ONLY) {
+        return;   // (the aggregated rows above are the output)
+      } else {
       auto store_block = [&](const f32x16& acc0, const f32x16& acc1, int n0, int rb) {   // rows [32 rb, 32 rb + 32) of the tile
         int fr = fr_c, kk = kk_c;   // (re-derived behind the accumulators: see the kernel above)
         asm volatile("" : "+v"(fr), "+v"(kk) : "v"(acc0[0]), "v"(acc1[15]));
@@ -1129,6 +1152,7 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
           }
         }
       }
+      }   // !AGG_ONLY
     };
     auto sync_advance = [&]() {
       if (cw == 0) PC_T(6);
@@ -1218,6 +1242,25 @@ static int launch_fused_pc_s(const FusedArgs& a, hipStream_t st) {
     if (a.val) hipLaunchKernelGGL((agg_dense_pc_kernel<W, true, MP_FUSED_U, KH, NCB, PF, true, false, TR, NP, NC, HAS_S>), grid, block, 0, st, a, ctr, nt);
     else hipLaunchKernelGGL((agg_dense_pc_kernel<W, false, MP_FUSED_U, KH, NCB, PF, true, false, TR, NP, NC, HAS_S>), grid, block, 0, st, a, ctr, nt);
   }
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// the aggregation alone on the producer/consumer structure: out = reduce_j w_ij x[j] (+ self_scale * S), sum / mean
+template <int W, int KH, int TR, int NP>
+static int launch_agg_tiles(const FusedArgs& a, hipStream_t st) {
+  const int64_t n_tiles = ceil_div(a.N, TR);
+  unsigned int* ctr = nullptr;
+  const int rc = pc_counter(&ctr, st);
+  if (rc != MP_OK) return rc;
+  const int64_t resident = (TR == 64 ? 1 : 2) * kNumCU;
+  const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident)), block((NP + 4) * kWave);
+  const int32_t nt = (int32_t)n_tiles;
+#define MP_AGG_TILES(WV, SV) \
+  hipLaunchKernelGGL((agg_dense_pc_kernel<W, WV, MP_FUSED_U, KH, 1, 1, true, false, TR, NP, 4, SV, true>), grid, block, 0, st, a, ctr, nt)
+  if (a.val) { if (a.S) MP_AGG_TILES(true, true); else MP_AGG_TILES(true, false); }
+  else { if (a.S) MP_AGG_TILES(false, true); else MP_AGG_TILES(false, false); }
+#undef MP_AGG_TILES
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -1351,6 +1394,32 @@ static int agg_dense_common(const int32_t* rowptr, const int32_t* col, const flo
     case 2: return launch_fused<2, 1, 1, 1>(a, st);
     default: return launch_fused<1, 1, 1, 1>(a, st);
   }
+}
+
+int mp_agg_rows_tiles_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,
+                          const float* X, int64_t ldx, int32_t F, const float* S, int64_t lds, float self_scale,
+                          float* out, int64_t ldo, mp_stream_t stream) {
+  if (!rowptr || !X || !out || N < 0 || F <= 0) return MP_ERR_INVALID_ARG;
+  if (ldx < F || ldo < F || (S && lds < F)) return MP_ERR_INVALID_ARG;
+  if (reduce != MP_SUM && reduce != MP_MEAN) return MP_ERR_INVALID_ARG;
+  if (reduce == MP_MEAN && S) return MP_ERR_INVALID_ARG;
+  if (F != 256 && F != 512) return MP_ERR_UNSUPPORTED;
+  if (N >= INT32_MAX - 64) return MP_ERR_UNSUPPORTED;
+  auto mis = [](const void* p, int64_t ld, int bytes) { return ((uintptr_t)p % bytes) || ((ld * 4) % bytes); };
+  if (mis(X, ldx, 16) || (S && mis(S, lds, 16)) || mis(out, ldo, 16)) return MP_ERR_ALIGNMENT;
+  if (N == 0) return MP_OK;
+  if (!col) return MP_ERR_INVALID_ARG;
+  FusedArgs a;
+  a.rowptr = rowptr; a.col = col; a.val = val; a.N = (int32_t)N;
+  a.X = X; a.ldx = ldx; a.S = S; a.lds = lds; a.self_scale = self_scale;
+  a.Wm = nullptr; a.ldw = 0; a.bias = nullptr; a.act = MP_ACT_NONE; a.defer_act = nullptr;
+  a.Wsp = nullptr; a.ldws = F;
+  a.P = out; a.ldp = ldo; a.out = out; a.ldo = ldo; a.dout = F; a.mean = reduce == MP_MEAN;
+  a.R = nullptr; a.ldr = 0;
+  a.out_vec4 = true;
+  hipStream_t st = as_stream(stream);
+  if (F == 512) return launch_agg_tiles<4, 2, 64, 4>(a, st);
+  return launch_agg_tiles<4, 1, 64, 4>(a, st);
 }
 
 int mp_agg_dense_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int reduce,

@@ -302,7 +302,7 @@ def test_c4_sage_concat_and_fused_mlp_head_at_10m(dev, big_graph):
     assert_close_rows(out[rows], ref64, 1e-5, ref32=ref32, what="C4 fused GIN head")
 
 
-def test_c5_d512_aggregation_and_two_branch_at_10m(dev, big_graph):
+def test_c5_d512_aggregation_and_two_branch_at_10m(dev, big_graph, monkeypatch):
     """config C5 operators at full size, d = 512: the GCN-normalised weighted sum, the GIN combine, and the ID-GNN
     two-branch aggregation (P = A x, Q = A S x in one pass, TfgIDLayer.py:510-517) with 1 % identity nodes"""
     from graphgym_amd import ops
@@ -322,14 +322,20 @@ def test_c5_d512_aggregation_and_two_branch_at_10m(dev, big_graph):
     ids = torch.randperm(n, device=dev, generator=gen)[: n // 100]
     ids = torch.cat([torch.arange(0, 4, device=dev), ids[ids >= 4]])        # a few hubs among the identity nodes
     P, Q = ops.idgnn_aggregate(G, ids, x)
-    y = ops.spmm(G, x, "sum")
-    assert torch.equal(P, y)                                     # the first branch IS the plain aggregation
+    monkeypatch.setenv("MP_AGG_TILES", "0")                      # the plan-based kernel, which the two-branch form shares
+    y_plan = ops.spmm(G, x, "sum")
+    assert torch.equal(P, y_plan)                                # the first branch IS the plain aggregation
+    del y_plan
+    monkeypatch.delenv("MP_AGG_TILES")
+    y = ops.spmm(G, x, "sum")                                    # (what the product dispatches at d = 512: the tile kernel)
     r64, r32, _ = _sampled_aggregate(G, x, rows, "sum")
     assert_close_rows(y[rows], r64, 1e-5, ref32=r32, what="C5 weighted sum, d=512")
     del y, P
     xm = torch.zeros_like(x)
     xm[ids] = x[ids]
-    yq = ops.spmm(G, xm, "sum")                                  # A (S x) by the plain kernel
+    monkeypatch.setenv("MP_AGG_TILES", "0")
+    yq = ops.spmm(G, xm, "sum")                                  # A (S x) by the plain (plan-based) kernel
+    monkeypatch.delenv("MP_AGG_TILES")
     assert torch.equal(Q, yq)
     is_id = torch.zeros(n, dtype=torch.bool, device=dev)
     is_id[ids] = True

@@ -784,3 +784,53 @@ def test_additive_attention_coefficients_in_one_pass(dev, heads):
     close(asg.grad, (r64[2], r32[2]), what="d a_src", mag=torch.maximum(mag_src, r64[2].abs()))
     sums = torch.zeros(N, heads, dtype=torch.float64).index_add_(0, rows, alpha.detach().cpu().double())
     assert float((sums - 1.0).abs().max()) <= 1e-5                  # every row has its self loop: coefficients sum to 1
+
+
+# --------------------------------------------------------------------------- the aggregation on the tile structure
+@pytest.mark.parametrize("n,E,d,reduce,weighted,self_scale,hubs", [
+    (70_001, 600_000, 256, "sum", True, 0.0, True),
+    (66_000, 400_000, 256, "mean", False, 0.0, False),
+    (65_536, 500_000, 512, "sum", True, 1.5, True),
+    (90_017, 300_000, 512, "mean", True, 0.0, False),
+    (131_072, 0 + 64, 256, "sum", False, 0.0, False),          # almost every tile without a single entry
+])
+def test_tile_aggregation_matches_oracle_and_the_plan_kernel(dev, monkeypatch, n, E, d, reduce, weighted, self_scale, hubs):
+    """mp_agg_rows_tiles_f32 (what ops._raw_spmm dispatches for plain sum / mean at d = 256 / 512 from 2^16 rows):
+    against the float64 oracle per row, against the plan-based kernel (same values up to the order of a cut row's
+    partial sums), bitwise reproducible, and actually taken (MP_AGG_TILES=0 gives the plan kernel's bits)."""
+    import graphgym_amd as ga
+    from graphgym_amd import ops, _lib
+    g = torch.Generator().manual_seed(n + d)
+    dst = torch.randint(0, n, (E,), generator=g)
+    src = torch.randint(0, n, (E,), generator=g)
+    if hubs:                                           # a few rows with tens of thousands of entries: cut between waves
+        k = E // 3
+        dst[:k] = torch.randint(0, 4, (k,), generator=g) * 1000 + 17
+    ei = torch.stack([dst, src])
+    w = (torch.rand(E, generator=g) + 0.1) if weighted else None
+    x = torch.randn(n, d, generator=g)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, None if w is None else w.to(dev), dst_row=0)
+    red = _lib.REDUCE[reduce]
+    xd = x.to(dev)
+    S = xd if self_scale else None
+    monkeypatch.setenv("MP_AGG_TILES", "1")
+    y1, _ = ops._raw_spmm(G, xd, red, S=S, self_scale=self_scale)
+    y1b, _ = ops._raw_spmm(G, xd, red, S=S, self_scale=self_scale)
+    monkeypatch.setenv("MP_AGG_TILES", "0")
+    y0, _ = ops._raw_spmm(G, xd, red, S=S, self_scale=self_scale)
+    assert torch.equal(y1, y1b)
+
+    def ref(c):
+        adj = R.SparseAdj(ei, None if w is None else c(w), [n, n])
+        agg = adj @ c(x)
+        if reduce == "mean":
+            cnt = torch.zeros(n, dtype=agg.dtype).index_add_(0, ei[0], torch.ones(E, dtype=agg.dtype))
+            wsum = agg if w is None else torch.zeros_like(agg).index_add_(0, ei[0], c(x)[ei[1]] * c(w)[:, None])
+            agg = wsum / cnt.clamp(min=1)[:, None]
+        return agg + self_scale * c(x)
+    refs = both(ref)
+    close(y1, refs, what="tile aggregation")
+    close(y0, refs, what="plan-based aggregation")
+    diff = (y1 - y0).abs().amax(dim=1)
+    scale = y0.abs().amax(dim=1).clamp(min=1e-30)
+    assert float((diff / scale).max()) < 1e-5
