@@ -272,6 +272,13 @@ def run_aggregate(args, rank, world, dev):
 
     if rank == 0:
         achieved = balg / (launch_ms * 1e-3) / 1e9
+        from graphgym_amd import ops as _ops
+        tiles = (d in _ops.AGG_TILES_WIDTHS and n >= _ops.AGG_TILES_MIN_ROWS and os.environ.get("MP_AGG_TILES", "1") != "0"
+                 and g.max_row_entries() <= _ops.FUSED_MAX_ROW)
+        kernel_label = ("mp::agg_dense_pc_kernel<..., AGG_ONLY> through mp_agg_rows_tiles_f32 (64-row tiles gathered into "
+                        "two LDS buffers by 4 waves of a workgroup, stored by 4 others; what ops.spmm dispatches for "
+                        "sum / mean at d = 256 / 512)" if tiles else
+                        "mp::agg_rows_kernel<4,SUM,weighted> (+ hub pieces/finalize, same launch group)")
         gname = "BA" if args.graph == "ba" else "HK0.3"
         workload = f"gcn_norm_sum_d{d}_{gname}_n{n}_m{args.m}" + ("_perm" if args.permute else "")
         traffic, traffic_source = pmc_traffic(workload)
@@ -302,7 +309,7 @@ def run_aggregate(args, rank, world, dev):
                          "launch_ms_p10_p90": [pct(0.1), pct(0.9)],
                          "launch_ms_cold_median": cold[len(cold) // 2] if cold else None,
                          "cold_note": "512 MB memset between launches (L2 / Infinity Cache flushed)",
-                         "kernel": "mp::agg_rows_kernel<4,SUM,weighted> (+ hub pieces/finalize, same launch group)"},
+                         "kernel": kernel_label},
         }
         if backward is not None:
             res["backward"] = backward
