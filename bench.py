@@ -277,7 +277,7 @@ def run_aggregate(args, rank, world, dev):
                  and g.max_row_entries() <= _ops.FUSED_MAX_ROW)
         kernel_label = ("mp::agg_dense_pc_kernel<..., AGG_ONLY> through mp_agg_rows_tiles_f32 (64-row tiles gathered into "
                         "two LDS buffers by 4 waves of a workgroup, stored by 4 others; what ops.spmm dispatches for "
-                        "sum / mean at d = 256 / 512)" if tiles else
+                        "sum / mean at d = 128 / 256 / 512)" if tiles else
                         "mp::agg_rows_kernel<4,SUM,weighted> (+ hub pieces/finalize, same launch group)")
         gname = "BA" if args.graph == "ba" else "HK0.3"
         workload = f"gcn_norm_sum_d{d}_{gname}_n{n}_m{args.m}" + ("_perm" if args.permute else "")

@@ -25,8 +25,8 @@ def _f32c(t, name):
 
 def _raw_spmm(g, x, reduce, S=None, self_scale=0.0, bias=None, relu=False, want_argmax=False,
               col_override=None, out=None):
-    """one launch of mp_spmm_csr_f32 — or, for plain sum / mean at d = 256 / 512 on a large operator, of
-    mp_agg_rows_tiles_f32 (the same aggregation on the producer/consumer tile structure: ~5 % faster; MP_AGG_TILES=0
+    """one launch of mp_spmm_csr_f32 — or, for plain sum / mean at d = 128 / 256 / 512 on a large operator, of
+    mp_agg_rows_tiles_f32 (the same aggregation on the producer/consumer tile structure: 2-5 % faster; MP_AGG_TILES=0
     keeps the plan-based kernel) —; x [n_src, d] -> y [N, d] (written into `out` when given)"""
     L = lib()
     N, d = g.num_nodes, x.size(1)
@@ -169,7 +169,7 @@ def times_wt(g, W):
 
 
 FUSED_WIDTHS = (64, 128, 256, 512)
-AGG_TILES_WIDTHS = (256, 512)   # widths of mp_agg_rows_tiles_f32
+AGG_TILES_WIDTHS = (128, 256, 512)   # widths of mp_agg_rows_tiles_f32 (d = 128: 10.04 -> 9.85 ms; d = 64 stays on the plan-based kernel)
 AGG_TILES_MIN_ROWS = 1 << 16    # 64-row tiles drawn by one workgroup per CU: below ~2^14 tiles the plan-based kernel fills the chip better
 FUSED_MAX_ROW = 1 << 18      # longer rows (star-like hubs) go to the plan-based kernel, which spreads them over many waves
 

@@ -316,7 +316,7 @@ int mp_agg_dense_add_f32(const int32_t* rowptr, const int32_t* col, const float*
 /* The aggregation ALONE on the same workgroup structure (round 3): out[N, F] = reduce_j w_ij X[j] (+ self_scale * S) —
  * SparseAdj.matmul (sparse_adj.py:91-97), the same contract as mp_spmm_csr_f32 with reduce = MP_SUM | MP_MEAN and no
  * epilogue.  Four waves of a workgroup gather 64-row tiles into LDS while four others store the finished tile with
- * full-line non-temporal stores; tiles are drawn from a counter (no plan, no workspace).  F = 256 or 512, 16-byte
+ * full-line non-temporal stores; tiles are drawn from a counter (no plan, no workspace).  F = 128, 256 or 512, 16-byte
  * aligned rows, rows of at most 2^18 stored entries (longer rows: mp_spmm_csr_f32, whose plan spreads them over many
  * waves); MP_ERR_UNSUPPORTED otherwise.  Faster than the plan-based kernel at these widths (19.6 against 20.6 ms at
  * 10^7 rows, 1.1e8 entries, F = 256).  Bitwise reproducible; a row cut between two waves of a tile is summed in wave

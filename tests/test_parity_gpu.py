@@ -793,6 +793,8 @@ def test_additive_attention_coefficients_in_one_pass(dev, heads):
     (65_536, 500_000, 512, "sum", True, 1.5, True),
     (90_017, 300_000, 512, "mean", True, 0.0, False),
     (131_072, 0 + 64, 256, "sum", False, 0.0, False),          # almost every tile without a single entry
+    (80_003, 500_000, 128, "sum", True, 0.5, True),
+    (65_537, 200_000, 128, "mean", False, 0.0, False),
 ])
 def test_tile_aggregation_matches_oracle_and_the_plan_kernel(dev, monkeypatch, n, E, d, reduce, weighted, self_scale, hubs):
     """mp_agg_rows_tiles_f32 (what ops._raw_spmm dispatches for plain sum / mean at d = 256 / 512 from 2^16 rows):
