@@ -1297,6 +1297,8 @@ static int launch_fused(const FusedArgs& a, hipStream_t st) {
     if constexpr (KH == 1) {
       if (v == 3) return launch_fused_pc<W, KH, 1, PF, 64, 4, 4, true>(a, st);
       if (a.dout > 256 && a.S != nullptr) return launch_fused_tiles<W, KH, NCB, PF>(a, st);   // (no self-term form with 8 consumers)
+      // small operators: 32-row tiles (twice the workgroups: 2 x 10^5 rows 0.57 vs 0.71 ms; 10^6 rows 2.13 vs 2.09)
+      if (a.N < (1 << 19) && a.dout <= 256) return launch_fused_pc<W, KH, NCB, PF, 32, 4, 4, true>(a, st);
       if (a.dout > 256) return launch_fused_pc<W, KH, 1, PF, 64, 4, 8>(a, st);   // one column block per consumer wave
       return launch_fused_pc<W, KH, 1, PF, 64, 4, 4, true>(a, st);
     } else {

@@ -37,6 +37,8 @@ def _raw_spmm(g, x, reduce, S=None, self_scale=0.0, bias=None, relu=False, want_
             and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0
             and (S is None or (S.stride(0) % 4 == 0 and S.data_ptr() % 16 == 0))
             and g.nnz > 0 and g.max_row_entries() <= FUSED_MAX_ROW):
+        global AGG_TILES_CALLS
+        AGG_TILES_CALLS += 1
         with torch.cuda.device(x.device):
             check(L.mp_agg_rows_tiles_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val), N, reduce, ptr(x), x.stride(0), d,
                                           ptr(S), S.stride(0) if S is not None else 0, float(self_scale),
@@ -169,8 +171,9 @@ def times_wt(g, W):
 
 
 FUSED_WIDTHS = (64, 128, 256, 512)
+AGG_TILES_CALLS = 0                   # launches of mp_agg_rows_tiles_f32 by this process (tests assert the dispatch)
 AGG_TILES_WIDTHS = (128, 256, 512)   # widths of mp_agg_rows_tiles_f32 (d = 128: 10.04 -> 9.85 ms; d = 64 stays on the plan-based kernel)
-AGG_TILES_MIN_ROWS = 1 << 16    # 64-row tiles drawn by one workgroup per CU: below ~2^14 tiles the plan-based kernel fills the chip better
+AGG_TILES_MIN_ROWS = 1 << 21    # crossover against the plan-based kernel on BA graphs (d = 256): 1e6 rows 2.15 vs 1.73 ms, 2e6 3.72 vs 3.82, 3e6 5.45 vs 5.82, 1e7 19.6 vs 20.6
 FUSED_MAX_ROW = 1 << 18      # longer rows (star-like hubs) go to the plan-based kernel, which spreads them over many waves
 
 

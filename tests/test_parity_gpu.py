@@ -797,7 +797,7 @@ def test_additive_attention_coefficients_in_one_pass(dev, heads):
     (65_537, 200_000, 128, "mean", False, 0.0, False),
 ])
 def test_tile_aggregation_matches_oracle_and_the_plan_kernel(dev, monkeypatch, n, E, d, reduce, weighted, self_scale, hubs):
-    """mp_agg_rows_tiles_f32 (what ops._raw_spmm dispatches for plain sum / mean at d = 256 / 512 from 2^16 rows):
+    """mp_agg_rows_tiles_f32 (what ops._raw_spmm dispatches for plain sum / mean at d = 128 / 256 / 512 from 2^21 rows):
     against the float64 oracle per row, against the plan-based kernel (same values up to the order of a cut row's
     partial sums), bitwise reproducible, and actually taken (MP_AGG_TILES=0 gives the plan kernel's bits)."""
     import graphgym_amd as ga
@@ -816,10 +816,14 @@ def test_tile_aggregation_matches_oracle_and_the_plan_kernel(dev, monkeypatch, n
     xd = x.to(dev)
     S = xd if self_scale else None
     monkeypatch.setenv("MP_AGG_TILES", "1")
+    monkeypatch.setattr(ops, "AGG_TILES_MIN_ROWS", 1)          # (the product dispatches it from 2^21 rows: test_configs_gpu C4 / C5)
+    before = ops.AGG_TILES_CALLS
     y1, _ = ops._raw_spmm(G, xd, red, S=S, self_scale=self_scale)
     y1b, _ = ops._raw_spmm(G, xd, red, S=S, self_scale=self_scale)
+    assert ops.AGG_TILES_CALLS == before + 2                    # the tile kernel ran
     monkeypatch.setenv("MP_AGG_TILES", "0")
     y0, _ = ops._raw_spmm(G, xd, red, S=S, self_scale=self_scale)
+    assert ops.AGG_TILES_CALLS == before + 2                    # ... and this was the plan-based one
     assert torch.equal(y1, y1b)
 
     def ref(c):
