@@ -1,9 +1,11 @@
-"""Randomised shapes / degree patterns for mp_agg_dense_f32 against the two-kernel order (aggregation kernel, then
-transform kernel): run boundaries that cut rows, empty tiles, rows past N, rows spanning several waves."""
+"""Randomised shapes / degree patterns for mp_agg_dense_f32 and mp_agg_rows_tiles_f32 against a float64 evaluation: run
+boundaries that cut rows, empty tiles, rows past N, rows spanning several waves, F = 64 ... 512, every kernel variant
+(MP_FUSED_VARIANT=1 / 3 / 9 in the environment: 32-row / 64-row producer-consumer, one-role kernel)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from graphgym_amd import ops
+from graphgym_amd import ops, _lib
+ops.AGG_TILES_MIN_ROWS = 1          # the tile aggregation at every size
 from graphgym_amd.graph import CSRGraph
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(int(os.environ.get("SEED", "0")))
@@ -11,9 +13,9 @@ def ri(lo, hi):
     return int(torch.randint(lo, hi + 1, (1,), generator=g))
 worst = 0.0
 for case in range(int(os.environ.get("CASES", "300"))):
-    n = ri(1, 400) if case % 3 else ri(1, 5000)
-    F = (64, 128, 256)[ri(0, 2)]
-    d = 2 * ri(1, 160)
+    n = ri(1, 400) if case % 3 else (ri(1, 5000) if case % 7 else ri(5000, 60000))
+    F = (64, 128, 256, 512)[ri(0, 3)]
+    d = 2 * ri(1, 160) if F < 512 or ri(0, 2) else (512, 384, 256)[ri(0, 2)]
     style = ri(0, 4)
     if style == 0:      # uniform sparse
         E = ri(0, 6 * n)
@@ -63,8 +65,14 @@ for case in range(int(os.environ.get("CASES", "300"))):
     ref = torch.relu(pre) if relu else pre
     eP = float(((P.double() - agg).abs() / mag.clamp_min(1.0)).max())
     eO = float(((out.double() - ref).abs() / pmag.clamp_min(1.0)).max())
-    worst = max(worst, eP, eO)
-    if eP > 1e-5 or eO > 1e-5:
-        print("MISMATCH", case, n, F, d, style, weighted, relu, mean, s, eP, eO, flush=True)
+    eT = 0.0
+    if F in ops.AGG_TILES_WIDTHS:       # the aggregation alone on the tile structure
+        before = ops.AGG_TILES_CALLS
+        yt, _ = ops._raw_spmm(G, x, red, S=x if s else None, self_scale=s)
+        assert ops.AGG_TILES_CALLS == before + 1
+        eT = float(((yt.double() - agg).abs() / mag.clamp_min(1.0)).max())
+    worst = max(worst, eP, eO, eT)
+    if eP > 1e-5 or eO > 1e-5 or eT > 1e-5:
+        print("MISMATCH", case, n, F, d, style, weighted, relu, mean, s, eP, eO, eT, flush=True)
         sys.exit(1)
 print("cases ok, worst relative error", worst)
