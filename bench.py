@@ -3,8 +3,14 @@
 GCN d=256 on 100M-edge scale-free").
 
     python bench.py --gpus 1 --steps 50 --warmup 20
+    python bench.py --gpus N --steps K --warmup W          # no launcher: bench.py starts its N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W [--mode step]
+
+On N > 1 GPUs the ONE line carries both: the weak-scaling aggregate (`value`, `roofline` with the fraction of
+N x 8 TB/s) and a `step` object — the data-parallel ID-GNN training step whose gradients cross RCCL
+(`collective_backend`, `world_size`, `allreduce_ms`, `allreduce_exposed_ms`, `lpt_imbalance`, `ms_per_step` next to
+`ms_per_step_no_exchange`; graphgym_amd/bench_step.py).
 
 --mode aggregate (default): a step is one pass of the aggregation  Y = A_hat X  over one graph resident
 in HBM: A_hat = D^-1/2 (A + I) D^-1/2 of a Barabasi-Albert BA(10^7, 5) graph (about 1.1*10^8 stored
@@ -214,6 +220,7 @@ def run_aggregate(args, rank, world, dev):
     copy_gbps = 2 * x.numel() * 4 / (copy_ms * 1e-3) / 1e9
 
     balg = algorithmic_bytes(n, g.nnz, d, g.val is not None)
+    balg_total = D.all_reduce_sum(balg, dev)
 
     # side legs (after the timed region, never part of `value`): the same launch into a buffer exactly as torch hands it
     # out, unchecked, and into the best of 8 checked candidates
@@ -270,6 +277,7 @@ def run_aggregate(args, rank, world, dev):
         except Exception as e:   # never let the side measurement take the metric down
             layer = {"error": repr(e)[:200]}
 
+    res = None
     if rank == 0:
         achieved = balg / (launch_ms * 1e-3) / 1e9
         from graphgym_amd import ops as _ops
@@ -317,8 +325,72 @@ def run_aggregate(args, rank, world, dev):
             res["layer"] = layer
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(g, x)
-        print(json.dumps(res), flush=True)
+        if world > 1:
+            # the whole job against the whole job's roof: N independent HBM systems
+            rf = res["roofline"]
+            rf["achieved_all_gpus"] = balg_total / (res["ms_per_step"] * 1e-3) / 1e9
+            rf["peak_all_gpus"] = HBM_PEAK_GBS * world
+            rf["frac_all_gpus"] = rf["achieved_all_gpus"] / rf["peak_all_gpus"]
+            rf["note"] = ("achieved / frac: rank 0's launches by HIP events; *_all_gpus: every rank's algorithmic bytes over "
+                          "the barrier-bracketed max-over-ranks step time, against world x 8 TB/s")
     D.barrier()
+    return res if rank == 0 else None
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it (the driver's command): start N fresh rank processes of this
+    same script — one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment — relay rank 0's stdout
+    (the one JSON line) and return the first non-zero exit code.  This parent never touches the GPU and never replaces
+    itself (no exec of a process that has initialised HIP); a rank that dies takes the others down (exact PIDs) instead of
+    leaving them in a collective."""
+    import signal
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MP_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        # rank 0's stdout is the protocol; the other ranks' stdout joins stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr, cwd=os.getcwd()))
+    rc = 0
+    alive = list(procs)
+    try:
+        while alive:
+            time.sleep(0.2)
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in alive:           # the others would wait for it in a barrier forever
+                        q.send_signal(signal.SIGTERM)
+            if rc != 0 and alive:
+                t_end = time.time() + 15
+                while alive and time.time() < t_end:
+                    time.sleep(0.2)
+                    alive = [q for q in alive if q.poll() is None]
+                for q in alive:
+                    q.kill()
+                alive = []
+    except KeyboardInterrupt:
+        for q in alive:
+            q.kill()
+        raise
+    return rc if rc >= 0 else 128 - rc
 
 
 def main():
@@ -326,7 +398,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--mode", choices=["aggregate", "step"], default="aggregate")
+    ap.add_argument("--mode", choices=["auto", "aggregate", "step", "both"], default="auto",
+                    help="auto = aggregate on one GPU; on N > 1 GPUs the aggregate line plus a `step` object (the "
+                         "data-parallel training step that contains the RCCL gradient all-reduce)")
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--m", type=int, default=5)
     ap.add_argument("--d", type=int, default=256)
@@ -334,29 +408,54 @@ def main():
                     help="ba = Barabasi-Albert (default); powerlaw_cluster = Holme-Kim with triangle probability 0.3")
     ap.add_argument("--permute", action="store_true", help="relabel nodes by a random permutation (seed 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--centres", type=int, default=4096, help="--mode step: ego-net centres in the global batch")
+    ap.add_argument("--centres", type=int, default=4096, help="step: ego-net centres per GPU in the global batch")
+    ap.add_argument("--step-model", choices=["idgcn", "idgin"], default="idgcn")
+    ap.add_argument("--step-steps", type=int, default=20, help="timed steps of the `step` object in --mode both")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # no launcher set the ranks up: be the launcher (before anything in this process touches the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     from graphgym_amd import dist as D
 
-    if args.mode == "step" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    mode = args.mode
+    if mode == "auto":
+        mode = "aggregate" if args.gpus == 1 else "both"
+    if mode == "step" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         # a one-rank step still EXECUTES its exchange (a one-rank RCCL group runs the same communicator set-up, stream
         # hand-off and async work objects as an 8-rank one): nothing RCCL-side is first run when the node appears
         os.environ.setdefault("MP_DIST_FORCE", "1")
         if "MASTER_PORT" not in os.environ:
-            import socket
-            s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+            os.environ["MASTER_PORT"] = str(_free_port())
     rank, local, world = D.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", torch.cuda.current_device())
-    if args.mode == "step":
+    res = None
+    if mode in ("aggregate", "both"):
+        res = run_aggregate(args, rank, world, dev)
+    if mode in ("step", "both"):
         from graphgym_amd import bench_step
-        bench_step.run(args, rank, world, dev)
-    else:
-        run_aggregate(args, rank, world, dev)
+        if mode == "both":
+            import copy
+            sargs = copy.copy(args)
+            sargs.steps, sargs.warmup = args.step_steps, 3
+            torch.cuda.empty_cache()
+            step = bench_step.run(sargs, rank, world, dev)
+            if rank == 0:
+                res["step"] = step
+        else:
+            res = bench_step.run(args, rank, world, dev)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    D.barrier()
+    if D.dist.is_available() and D.dist.is_initialized():
+        D.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -87,12 +87,21 @@ PROTOTYPES = {
     "mp_sddmm_grad_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _p]),
     "mp_spmm_csr_heads_f32": (C.c_int, [_p, _p, _p, _i64, _p, _pi32, _i32, _p, _i64, _p, _i64, _i32, _p, _sz, _p]),
     "mp_spmm_heads_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _p]),
-    "mp_ego_ws_bytes": (C.c_int, [_i64, _i64, _psz]),
-    "mp_ego_expand_count": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _sz, _p, _p]),
-    "mp_ego_expand_emit": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _sz, _p, _p, _p, _p, _p]),
+    "mp_ego_expand": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "mp_gen_ba_edges_host": (C.c_int, [_i64, _i32, C.c_uint64, _p, _p, _p]),
     "mp_gen_powerlaw_cluster_edges_host": (C.c_int, [_i64, _i32, C.c_double, C.c_uint64, _p, _p, _p]),
 }
+
+# callback types of mp_ego_expand (mp_engine.h: mp_alloc_fn, mp_free_fn, mp_ego_result_t)
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p)
+FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
+class EgoResult(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("n_edges", C.c_int64), ("src", C.c_void_p), ("dst", C.c_void_p),
+                ("orig", C.c_void_p), ("ego_of", C.c_void_p), ("candidates", C.c_int64),
+                ("scratch_peak_bytes", C.c_size_t)]
+
 
 _lib = None
 

@@ -116,6 +116,7 @@ def run(args, rank, world, dev):
     total_nnz = D.all_reduce_sum(nnz_local, dev)
     total_nodes = D.all_reduce_sum(int(orig.numel()), dev)
     max_nnz = D.all_reduce_max(nnz_local, dev)
+    res = None
     if rank == 0:
         n_par = sum(p.numel() for p in model.parameters())
         res = {
@@ -128,6 +129,7 @@ def run(args, rank, world, dev):
             "allreduce_exposed_ms": exposed, "allreduce_ms": t_ar * 1e3,
             "allreduce_bytes": 4 * n_par, "allreduce_buckets": len(bucket.buckets),
             "collective_backend": D.dist.get_backend() if D.dist.is_initialized() else None,
+            "world_size": D.dist.get_world_size() if D.dist.is_initialized() else 1,
             "collectives_executed": bool(bucket._active()),
             "step_efficiency_vs_no_exchange": dt_local / dt,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -143,5 +145,5 @@ def run(args, rank, world, dev):
                        "parallelism": f"dp{world}: ego nets sharded by stored entries (LPT), gradient all-reduce "
                                       f"(RCCL, 2 buckets, overlapped with backward)"},
         }
-        print(json.dumps(res), flush=True)
     D.barrier()
+    return res

@@ -32,6 +32,25 @@ void set_hip_error(hipError_t e, const char* what);
     }                                                  \
   } while (0)
 
+// Workgroup barrier of the ROLE-SPLIT kernels (fused.hip agg_dense_pc_kernel, gemm.hip dense_wgrad_pc_kernel,
+// dense_x3.hip dense_x3_pc_kernel): the waves of a workgroup are divided into roles by whole waves (wave-uniform), each
+// role runs its OWN loop over the same item sequence, and the loops meet at barriers that pair up BY COUNT — gfx9's
+// s_barrier counts arriving waves wherever they are in the code.  HIP's __syncthreads() promises a barrier only where
+// every thread of the block reaches the SAME call, so these sites do not use it: they state the hardware instruction
+// and the fences it needs themselves —
+//   release fence (workgroup): this wave's LDS writes (and its prior global writes, as far as the workgroup sees them)
+//                              are complete before it arrives: s_waitcnt lgkmcnt(0) on gfx950, no vmcnt wait, so
+//                              global LOADS in flight stay in flight across the barrier (the kernels rely on that);
+//   s_barrier;
+//   acquire fence (workgroup): nothing after the barrier is hoisted above it.
+// tests/test_emitted_barriers.py disassembles the built code objects and checks, per instantiation, that each role loop
+// holds exactly the barriers its source holds (no merge, hoist or duplication by the compiler).
+__device__ __forceinline__ void role_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 static inline hipStream_t as_stream(mp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

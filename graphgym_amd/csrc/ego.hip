@@ -1,305 +1,438 @@
 // GPU ego-net batcher: the ID-GNN "Full" sampler of graphgym/models/transform.py:11-38 for a
-// batch of centre nodes, on the device.
+// batch of centre nodes, on the device — with cost that follows the EGO NETS, not the graph.
 //
 // The reference loops over every node in Python (nx.ego_graph + nx.relabel_nodes), a ~60x data
-// blow-up built on one CPU thread.  Here a batch of B centres is expanded at once:
-//   * one bitmap of N bits per centre; `radius` level-synchronous sweeps mark the members
-//     (frontier bitmap -> atomicOr into visited / next), radius > 4 means the whole graph
-//     (transform.py:18-19);
-//   * new ids follow the reference: centre c keeps id c (0..B-1), the other members of ego c get
-//     fresh consecutive ids in ascending original-id order (the order nx's subgraph view iterates),
-//     egos laid out one after another (transform.py:24-36);
-//   * the induced edges are emitted as a COO list in the new ids; `orig` maps every new node back
-//     to its original id (to gather features / labels).
-// The COO goes straight into mp_csr_from_coo; node_id_index is arange(B) (transform.py:38).
+// blow-up built on one CPU thread.  Rounds 1-3 kept one N-bit bitmap per centre (four [B, N/32]
+// word arrays, every sweep scanning all of them): B * N / 2 bytes — 20 GB at N = 10^7, B = 4096.
+// This version holds only the members:
+//
+//   * a member is a 64-bit key  (ego c) << 33 | (original node u) << 1 | fresh-bit ; the member
+//     list is ONE array sorted by (c, u) — which is the id order of transform.py:24-36: egos one
+//     after another, inside an ego ascending original id;
+//   * one level of the breadth-first expansion: the members added by the previous level (fresh
+//     bit set) push their neighbour lists as candidate keys (one thread per candidate: balanced
+//     whatever the degrees, a 10^4-neighbour hub is 10^4 threads), members + candidates are
+//     radix-sorted on the key bits in use, and a unique pass keeps the first of every (c, u) run —
+//     an old member sorts in front of a candidate with the same (c, u), so the survivor's fresh
+//     bit says whether it is new.  `radius` such levels (transform.py:19: nx.ego_graph(G, i,
+//     radius)); radius > 4 takes every node of the graph (transform.py:17-18) — the member list
+//     is then written directly;
+//   * new ids: the centre of ego c keeps id c (0..B-1); the member at sorted position p of ego c
+//     gets B + p - c - [u > centre_c]: egos laid out one after another, fresh ids ascending with
+//     the original id (transform.py:27-33; the order of fresh ids INSIDE an ego is the iteration
+//     order of a Python set in the reference, i.e. not defined by it);
+//   * induced edges: a wave per member walks the member's neighbour list; a neighbour belongs to
+//     the ego iff its (c, u) key is in the member list — a 1-load test against a 16-bit-per-member
+//     hash filter (L2 resident) in front of a binary search inside the ego's segment.  Pass 1
+//     counts, an exclusive scan places every member's edges (ordered: by destination member, then
+//     by source — no atomics, same output every run), pass 2 emits COO in the new ids together
+//     with `orig` (new id -> original id) and `ego_of`.
+//
+// Memory: every buffer is sized by members + candidates of the level at hand; the caller's
+// allocator hands them out (mp_alloc_fn: torch's caching allocator through ctypes) and takes them
+// back as soon as a level is done.  Peak scratch is ~45 B per emitted node; nothing scales with N.
+// The host reads three counters per level (one stream synchronisation each): sizes are data.
 #include "common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace mp {
 
-struct EgoWs {
-  uint32_t* visited;   // [B, W]
-  uint32_t* frontier;  // [B, W]
-  uint32_t* next;      // [B, W]
-  int32_t* wprefix;    // [B, W]  members before word w
-  int32_t* members;    // [B]
-  int64_t* node_off;   // [B+1]   first fresh id of ego c (node_off[0] = B)
-  int64_t* edge_cnt;   // [B]
-  int64_t* edge_off;   // [B+1]
-  unsigned long long* cursor;  // [B]
-  size_t total;
+__device__ __host__ __forceinline__ uint64_t ego_key(uint64_t c, uint64_t u, uint64_t fresh) {
+  return (c << 33) | (u << 1) | fresh;
+}
+__device__ __forceinline__ uint32_t key_c(uint64_t k) { return (uint32_t)(k >> 33); }
+__device__ __forceinline__ uint32_t key_u(uint64_t k) { return (uint32_t)(k >> 1) & 0x7fffffffu; }
+
+// degree of member i if it was added by the previous level, else 0; 0 past the device-side count
+struct FreshDegree {
+  const uint64_t* keys;
+  const int32_t* rowptr;
+  const int64_t* count;
+  __device__ int64_t operator()(int64_t i) const {
+    if (i >= *count) return 0;
+    const uint64_t k = keys[i];
+    if (!(k & 1ull)) return 0;
+    const uint32_t u = key_u(k);
+    return (int64_t)(rowptr[u + 1] - rowptr[u]);
+  }
 };
 
-static void ego_layout(int64_t N, int64_t B, void* base, EgoWs* w) {
-  const size_t W = (size_t)ceil_div(N, 32);
-  char* p = (char*)base;
-  size_t off = 0;
-  auto take = [&](size_t bytes) { void* r = p ? p + off : nullptr; off += align_up(bytes, 256); return r; };
-  w->visited = (uint32_t*)take(B * W * 4);
-  w->frontier = (uint32_t*)take(B * W * 4);
-  w->next = (uint32_t*)take(B * W * 4);
-  w->wprefix = (int32_t*)take(B * W * 4);
-  w->members = (int32_t*)take(B * 4);
-  w->node_off = (int64_t*)take((B + 1) * 8);
-  w->edge_cnt = (int64_t*)take(B * 8);
-  w->edge_off = (int64_t*)take((B + 1) * 8);
-  w->cursor = (unsigned long long*)take(B * 8);
-  w->total = off;
-}
+struct SameMember {   // equality of (c, u), the fresh bit aside
+  __device__ bool operator()(uint64_t a, uint64_t b) const { return (a >> 1) == (b >> 1); }
+};
 
 __global__ __launch_bounds__(kBlock) void ego_seed_kernel(const int64_t* __restrict__ centres, int64_t B,
-                                                          int64_t W, int whole_graph, int64_t N,
-                                                          uint32_t* visited, uint32_t* frontier) {
-  // whole_graph: every bit of [0, N) set (radius > 4); else only the centre's bit
-  const int64_t total = B * W;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t c = i / W, w = i - c * W;
-    uint32_t bits = 0;
-    if (whole_graph) {
-      const int64_t lo = w * 32;
-      const int64_t n = N - lo >= 32 ? 32 : N - lo;
-      bits = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
-    } else {
-      const int64_t v = centres[c];
-      if ((v >> 5) == w) bits = 1u << (v & 31);
-    }
-    visited[i] = bits;
-    frontier[i] = whole_graph ? 0u : bits;
+                                                          uint64_t* members, int64_t* count) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < B) members[c] = ego_key((uint64_t)c, (uint64_t)centres[c], 1);
+  if (c == 0) *count = B;
+}
+
+// radius > 4: every node of the graph is a member of every ego (transform.py:17-18)
+__global__ __launch_bounds__(kBlock) void ego_whole_kernel(int64_t B, int64_t N, uint64_t* members) {
+  const int64_t total = B * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i / N;
+    members[i] = ego_key((uint64_t)c, (uint64_t)(i - c * N), 0);
   }
 }
 
-// Wave-wide walk over the set bits of a bitmap: a wave loads 64 words at once, skips empty ones with a
-// ballot, and hands every member node v to `body(v)` with v wave-uniform — so the 64 lanes can split
-// v's neighbour list (coalesced col reads; a 10^4-neighbour hub no longer serialises one thread).
-template <class Body>
-__device__ __forceinline__ void for_each_member(const uint32_t* __restrict__ bitmap, int64_t W, Body body) {
+// keys_in[0, M) = the members with the fresh bit cleared; keys_in[M + q] = candidate q: neighbour j of the fresh member i
+// with offs[i] <= q < offs[i + 1] (one thread per candidate, i by binary search)
+__global__ __launch_bounds__(kBlock) void ego_fill_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                          const uint64_t* __restrict__ members, int64_t M,
+                                                          const int64_t* __restrict__ offs, int64_t C,
+                                                          uint64_t* __restrict__ keys_in) {
+  const int64_t total = M + C;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    if (t < M) {
+      keys_in[t] = members[t] & ~1ull;
+      continue;
+    }
+    const int64_t q = t - M;
+    int64_t lo = 0, hi = M;                 // last i with offs[i] <= q
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (offs[mid] <= q) lo = mid; else hi = mid;
+    }
+    const uint64_t k = members[lo];
+    const uint32_t u = key_u(k);
+    const uint32_t nb = (uint32_t)col[rowptr[u] + (int32_t)(q - offs[lo])] & 0x7fffffffu;
+    keys_in[t] = ego_key(key_c(k), nb, 1);
+  }
+}
+
+// seg[c] = first member of ego c (c = 0..B; seg[B] = M)
+__global__ __launch_bounds__(kBlock) void ego_seg_kernel(const uint64_t* __restrict__ members, int64_t M, int64_t B,
+                                                         int64_t* __restrict__ seg) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > B) return;
+  const uint64_t want = ego_key((uint64_t)c, 0, 0);
+  int64_t lo = 0, hi = M;                   // first i with members[i] >= want
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (members[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  seg[c] = lo;
+}
+
+__device__ __forceinline__ uint32_t ego_hash(uint32_t c, uint32_t u) {
+  uint32_t h = u * 0x9E3779B1u ^ (c + 0x7F4A7C15u) * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  return h ^ (h >> 13);
+}
+
+// the member ids as 32-bit words (the searches read half the bytes) and the hash filter: one bit per member among
+// `fbits` = 2^k >= 16 M
+__global__ __launch_bounds__(kBlock) void ego_index_kernel(const uint64_t* __restrict__ members, int64_t M,
+                                                           uint32_t* __restrict__ mu, uint32_t* __restrict__ filter,
+                                                           uint32_t fmask) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t k = members[i];
+    const uint32_t u = key_u(k);
+    mu[i] = u;
+    if (filter) {
+      const uint32_t h = ego_hash(key_c(k), u) & fmask;
+      atomicOr(&filter[h >> 5], 1u << (h & 31));
+    }
+  }
+}
+
+// position of (c, u) in the member list, or -1
+__device__ __forceinline__ int64_t ego_find(const uint32_t* __restrict__ mu, int64_t s, int64_t e, uint32_t u) {
+  while (s < e) {
+    const int64_t mid = (s + e) >> 1;
+    const uint32_t v = mu[mid];
+    if (v < u) s = mid + 1; else e = mid;
+  }
+  return s;   // lower bound; the caller compares
+}
+
+// PASS 0: cnt[p] = induced in-edges of member p.  PASS 1: emit them at eoff[p]..., and orig / ego_of of p's new id.
+// One wave per member; WHOLE: every node is a member, position = c N + u.
+template <int PASS, bool WHOLE>
+__global__ __launch_bounds__(kBlock) void ego_edges_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                           const int64_t* __restrict__ centres, int64_t B, int64_t N,
+                                                           const uint64_t* __restrict__ members, int64_t M,
+                                                           const uint32_t* __restrict__ mu, const int64_t* __restrict__ seg,
+                                                           const uint32_t* __restrict__ filter, uint32_t fmask,
+                                                           int32_t* __restrict__ cnt, const int64_t* __restrict__ eoff,
+                                                           int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst,
+                                                           int64_t* __restrict__ orig, int32_t* __restrict__ ego_of) {
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * kWave;
-  for (int64_t wbase = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kWave; wbase < W; wbase += stride) {
-    const int64_t w = wbase + lane;
-    const uint32_t mine = w < W ? bitmap[w] : 0u;
-    unsigned long long nz = __ballot(mine != 0u);
-    while (nz) {
-      const int src = __builtin_ctzll(nz);
-      nz &= nz - 1;
-      uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)mine, src);
-      while (bits) {
-        const int b = __builtin_ctz(bits);
-        bits &= bits - 1;
-        body((uint32_t)((wbase + src) * 32 + b));
-      }
-    }
-  }
-}
-
-// one BFS level: grid (chunks, B); every member of `frontier` pushes its neighbours
-__global__ __launch_bounds__(kBlock) void ego_level_kernel(const int32_t* __restrict__ rowptr,
-                                                           const int32_t* __restrict__ col, int64_t W,
-                                                           const uint32_t* __restrict__ frontier,
-                                                           uint32_t* visited, uint32_t* next) {
-  const int64_t c = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  uint32_t* vis = visited + c * W;
-  uint32_t* nx = next + c * W;
-  for_each_member(frontier + c * W, W, [&](uint32_t v) {
-    const int s = rowptr[v], e = rowptr[v + 1];
-    for (int k = s + lane; k < e; k += kWave) {
-      const uint32_t u = (uint32_t)col[k] & 0x7fffffffu;
-      const uint32_t m = 1u << (u & 31);
-      if (!(vis[u >> 5] & m)) {
-        const uint32_t old = atomicOr(&vis[u >> 5], m);
-        if (!(old & m)) atomicOr(&nx[u >> 5], m);
-      }
-    }
-  });
-}
-
-// per centre: exclusive prefix of popcounts over the bitmap words; one workgroup per centre
-__global__ __launch_bounds__(kBlock) void ego_prefix_kernel(const uint32_t* __restrict__ visited, int64_t W,
-                                                            int32_t* wprefix, int32_t* members) {
-  __shared__ int32_t part[kBlock];
-  __shared__ int32_t carry_s;
-  const int64_t c = blockIdx.x;
-  const uint32_t* vis = visited + c * W;
-  int32_t* wp = wprefix + c * W;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int64_t base = 0; base < W; base += kBlock) {
-    const int64_t w = base + threadIdx.x;
-    const int32_t cnt = w < W ? __popc(vis[w]) : 0;
-    part[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int off = 1; off < kBlock; off <<= 1) {   // Hillis-Steele inclusive scan
-      int32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-      __syncthreads();
-      part[threadIdx.x] += t;
-      __syncthreads();
-    }
-    const int32_t carry = carry_s;
-    if (w < W) wp[w] = carry + part[threadIdx.x] - cnt;
-    __syncthreads();
-    if (threadIdx.x == kBlock - 1) carry_s = carry + part[kBlock - 1];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) members[c] = carry_s;
-}
-
-// node_off[c] = B + sum_{c' < c} (members[c'] - 1); single workgroup, B is a batch size
-__global__ void ego_node_off_kernel(const int32_t* __restrict__ members, int64_t B, int64_t* node_off) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int64_t acc = B;
-    for (int64_t c = 0; c < B; ++c) { node_off[c] = acc; acc += members[c] - 1; }
-    node_off[B] = acc;
-  }
-}
-
-__device__ __forceinline__ int64_t ego_new_id(const uint32_t* vis, const int32_t* wp, int64_t node_off_c,
-                                              int64_t centre, int64_t c, uint32_t u) {
-  if ((int64_t)u == centre) return c;
-  const uint32_t word = vis[u >> 5];
-  int64_t rank = wp[u >> 5] + __popc(word & ((1u << (u & 31)) - 1u));
-  if ((int64_t)u > centre) rank -= 1;   // the centre is not among the fresh ids
-  return node_off_c + rank;
-}
-
-// pass 0: count induced edges per centre; pass 1: emit them (atomic cursor per centre) and orig ids
-template <int PASS>
-__global__ __launch_bounds__(kBlock) void ego_edges_kernel(const int32_t* __restrict__ rowptr,
-                                                           const int32_t* __restrict__ col, int64_t W,
-                                                           const int64_t* __restrict__ centres,
-                                                           const uint32_t* __restrict__ visited,
-                                                           const int32_t* __restrict__ wprefix,
-                                                           const int64_t* __restrict__ node_off,
-                                                           const int64_t* __restrict__ edge_off,
-                                                           int64_t* edge_cnt, unsigned long long* cursor,
-                                                           int64_t* out_src, int64_t* out_dst, int64_t* orig,
-                                                           int32_t* ego_of) {
-  const int64_t c = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const uint32_t* vis = visited + c * W;
-  const int32_t* wp = wprefix + c * W;
-  const int64_t centre = centres[c];
-  const int64_t noff = PASS ? node_off[c] : 0;
-  const int64_t eoff = PASS ? edge_off[c] : 0;
-  long long local = 0;
-  for_each_member(vis, W, [&](uint32_t v) {
-    const int s = rowptr[v], e = rowptr[v + 1];
-    int64_t vid = 0;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t p = wave0; p < M; p += nwaves) {
+    const uint64_t k = members[p];
+    const uint32_t c = key_c(k), v = key_u(k);
+    const int64_t centre = centres[c];
+    const int64_t s0 = WHOLE ? (int64_t)c * N : seg[c];
+    const int64_t s1 = WHOLE ? s0 + N : seg[c + 1];
+    auto new_id = [&](int64_t q, uint32_t u) -> int64_t {
+      if ((int64_t)u == centre) return (int64_t)c;
+      return B + q - (int64_t)c - ((int64_t)u > centre ? 1 : 0);
+    };
+    int64_t vid = 0, base = 0;
     if (PASS) {
-      vid = ego_new_id(vis, wp, noff, centre, c, v);
+      vid = new_id(p, v);
+      base = eoff[p];
       if (lane == 0) {
         orig[vid] = (int64_t)v;
         if (ego_of) ego_of[vid] = (int32_t)c;
       }
     }
-    for (int k = s + lane; k < e; k += kWave) {
-      const uint32_t u = (uint32_t)col[k] & 0x7fffffffu;
-      if (vis[u >> 5] & (1u << (u & 31))) {
-        if (PASS) {
-          const unsigned long long slot = atomicAdd(&cursor[c], 1ull);   // one add per wave after hipcc's coalescing
-          const int64_t o = eoff + (int64_t)slot;
-          out_dst[o] = vid;                                              // row v holds v's in-edges
-          out_src[o] = ego_new_id(vis, wp, noff, centre, c, u);
+    const int rs = rowptr[v], re = rowptr[v + 1];
+    int total = 0;
+    for (int j0 = rs; j0 < re; j0 += kWave) {
+      const int j = j0 + lane;
+      bool hit = false;
+      int64_t q = -1;
+      uint32_t u = 0;
+      if (j < re) {
+        u = (uint32_t)col[j] & 0x7fffffffu;
+        if (WHOLE) {
+          hit = true;
+          q = s0 + u;
         } else {
-          ++local;
+          bool maybe = true;
+          if (filter) {
+            const uint32_t h = ego_hash(c, u) & fmask;
+            maybe = (filter[h >> 5] >> (h & 31)) & 1u;
+          }
+          if (maybe) {
+            q = ego_find(mu, s0, s1, u);
+            hit = q < s1 && mu[q] == u;
+          }
         }
       }
+      const unsigned long long m = __ballot(hit);
+      if (PASS && hit) {
+        const int64_t o = base + total + __popcll(m & ((1ull << lane) - 1ull));
+        out_dst[o] = vid;                     // row v holds v's in-edges
+        out_src[o] = new_id(q, u);
+      }
+      total += (int)__popcll(m);
     }
-  });
-  if (!PASS) {
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, kWave);
-    if (lane == 0 && local) atomicAdd((unsigned long long*)&edge_cnt[c], (unsigned long long)local);
+    if (!PASS && lane == 0) cnt[p] = total;
   }
 }
 
-__global__ void ego_edge_off_kernel(const int64_t* __restrict__ edge_cnt, int64_t B, int64_t* edge_off) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int64_t acc = 0;
-    for (int64_t c = 0; c < B; ++c) { edge_off[c] = acc; acc += edge_cnt[c]; }
-    edge_off[B] = acc;
-  }
-}
+struct CountAsI64 {
+  const int32_t* cnt;
+  int64_t M;
+  __device__ int64_t operator()(int64_t i) const { return i < M ? (int64_t)cnt[i] : 0; }
+};
 
-static dim3 ego_grid(int64_t W, int64_t B) {
-  int64_t bx = ceil_div(W, kBlock);   // one wave per 64 words, four waves per block
-  if (bx < 1) bx = 1;
-  if (bx > 512) bx = 512;
-  return dim3((unsigned)bx, (unsigned)B);
+// ---- host side ----------------------------------------------------------------------------------------------------
+struct EgoMem {           // scratch through the caller's allocator, with the live total tracked
+  mp_alloc_fn alloc;
+  mp_free_fn release;
+  void* user;
+  size_t live = 0, peak = 0;
+  struct Blk { void* p; size_t n; };
+  Blk blks[32];
+  int nblk = 0;
+  void* take(size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    void* p = alloc(bytes, MP_EGO_TAG_SCRATCH, user);
+    if (!p) return nullptr;
+    if (nblk < 32) blks[nblk++] = {p, bytes};
+    live += bytes;
+    if (live > peak) peak = live;
+    return p;
+  }
+  void give(void* p) {
+    if (!p) return;
+    for (int i = 0; i < nblk; ++i)
+      if (blks[i].p == p) {
+        live -= blks[i].n;
+        blks[i] = blks[--nblk];
+        break;
+      }
+    if (release) release(p, user);
+  }
+  void give_all() {
+    while (nblk > 0) give(blks[nblk - 1].p);
+  }
+};
+
+static unsigned bits_for(uint64_t x) {   // bits needed to hold values < x
+  unsigned b = 0;
+  while (b < 63 && (1ull << b) < x) ++b;
+  return b;
 }
 
 }  // namespace mp
 
 using namespace mp;
 
+#define EGO_TAKE(var, type, bytes)                                  \
+  type* var = reinterpret_cast<type*>(mem.take((size_t)(bytes)));   \
+  if (!var) { mem.give_all(); return MP_ERR_WORKSPACE; }
+#define EGO_HIP(call)                                               \
+  do {                                                              \
+    hipError_t _e = (call);                                         \
+    if (_e != hipSuccess) {                                         \
+      ::mp::set_hip_error(_e, #call);                               \
+      mem.give_all();                                               \
+      return MP_ERR_HIP;                                            \
+    }                                                               \
+  } while (0)
+#define EGO_LAUNCH_CHECK() EGO_HIP(hipGetLastError())
+
 extern "C" {
 
-int mp_ego_ws_bytes(int64_t N, int64_t n_centres, size_t* bytes_host) {
-  if (!bytes_host || N < 0 || n_centres < 0) return MP_ERR_INVALID_ARG;
-  if (N >= INT32_MAX || n_centres > 65535) return MP_ERR_UNSUPPORTED;
-  EgoWs w;
-  ego_layout(N, n_centres, nullptr, &w);
-  *bytes_host = w.total;
-  return MP_OK;
-}
-
-int mp_ego_expand_count(const int32_t* rowptr, const int32_t* col, int64_t N, const int64_t* centres,
-                        int64_t n_centres, int32_t radius, void* ws, size_t ws_bytes, int64_t* counts_host,
-                        mp_stream_t stream) {
-  if (!rowptr || !centres || !counts_host || N <= 0 || n_centres <= 0 || radius < 0) return MP_ERR_INVALID_ARG;
-  if (N >= INT32_MAX || n_centres > 65535) return MP_ERR_UNSUPPORTED;
-  EgoWs L;
-  ego_layout(N, n_centres, ws, &L);
-  if (!ws || ws_bytes < L.total) return MP_ERR_WORKSPACE;
+int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N, const int64_t* centres, int64_t n_centres,
+                  int32_t radius, mp_alloc_fn alloc, mp_free_fn release, void* user, mp_ego_result_t* out,
+                  mp_stream_t stream) {
+  if (!rowptr || !centres || !alloc || !out || N <= 0 || n_centres <= 0 || radius < 0) return MP_ERR_INVALID_ARG;
+  if (!col && radius > 0) return MP_ERR_INVALID_ARG;
+  if (N >= INT32_MAX || n_centres >= (1ll << 30)) return MP_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
-  const int64_t B = n_centres, W = ceil_div(N, 32);
-  const int whole = radius > 4;   // transform.py:18-19
-  hipLaunchKernelGGL(ego_seed_kernel, dim3(flat_grid(B * W)), dim3(kBlock), 0, st, centres, B, W, whole, N,
-                     L.visited, L.frontier);
-  MP_LAUNCH_CHECK();
-  if (!whole) {
-    uint32_t* fr = L.frontier;
-    uint32_t* nx = L.next;
+  const int64_t B = n_centres;
+  const bool whole = radius > 4;   // transform.py:17-18
+  EgoMem mem{alloc, release, user};
+  *out = mp_ego_result_t{};
+  const unsigned end_bit = 33 + bits_for((uint64_t)B);
+
+  EGO_TAKE(count_d, int64_t, 64);             // [0] members, [1] unique count
+  int64_t M = B, cap = B, cand_total = 0;
+  uint64_t* members = nullptr;
+  if (whole) {
+    if (B > (int64_t)((1ull << 40) / (uint64_t)N)) { mem.give_all(); return MP_ERR_UNSUPPORTED; }
+    M = cap = B * N;
+    members = reinterpret_cast<uint64_t*>(mem.take((size_t)M * 8));
+    if (!members) { mem.give_all(); return MP_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(ego_whole_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, B, N, members);
+    EGO_LAUNCH_CHECK();
+  } else {
+    members = reinterpret_cast<uint64_t*>(mem.take((size_t)B * 8));
+    if (!members) { mem.give_all(); return MP_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(ego_seed_kernel, dim3((unsigned)ceil_div(B, kBlock)), dim3(kBlock), 0, st, centres, B, members,
+                       count_d);
+    EGO_LAUNCH_CHECK();
     for (int lvl = 0; lvl < radius; ++lvl) {
-      MP_HIP(hipMemsetAsync(nx, 0, (size_t)B * W * 4, st));
-      hipLaunchKernelGGL(ego_level_kernel, ego_grid(W, B), dim3(kBlock), 0, st, rowptr, col, W, fr, L.visited, nx);
-      MP_LAUNCH_CHECK();
-      uint32_t* t = fr; fr = nx; nx = t;
+      // candidates of this level: exclusive scan of the fresh members' degrees; offs[cap] = their number
+      EGO_TAKE(offs, int64_t, (size_t)(cap + 1) * 8);
+      auto deg_it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0),
+                                                     FreshDegree{members, rowptr, count_d});
+      size_t tb = 0;
+      EGO_HIP(rocprim::exclusive_scan(nullptr, tb, deg_it, offs, (int64_t)0, (size_t)(cap + 1), rocprim::plus<int64_t>(), st));
+      EGO_TAKE(tmp, char, tb);
+      EGO_HIP(rocprim::exclusive_scan(tmp, tb, deg_it, offs, (int64_t)0, (size_t)(cap + 1), rocprim::plus<int64_t>(), st));
+      int64_t host[2] = {0, 0};
+      EGO_HIP(hipMemcpyAsync(&host[0], count_d, 8, hipMemcpyDeviceToHost, st));
+      EGO_HIP(hipMemcpyAsync(&host[1], offs + cap, 8, hipMemcpyDeviceToHost, st));
+      EGO_HIP(hipStreamSynchronize(st));
+      mem.give(tmp);
+      M = host[0];
+      const int64_t C = host[1];
+      if (C == 0) {            // nothing to add: the expansion has reached its components' ends
+        mem.give(offs);
+        break;
+      }
+      if (M + C >= (1ll << 40)) { mem.give_all(); return MP_ERR_UNSUPPORTED; }
+      cand_total += C;
+      const int64_t T = M + C;
+      EGO_TAKE(keys_in, uint64_t, (size_t)T * 8);
+      hipLaunchKernelGGL(ego_fill_kernel, dim3(flat_grid(T)), dim3(kBlock), 0, st, rowptr, col, members, M, offs, C, keys_in);
+      EGO_LAUNCH_CHECK();
+      EGO_TAKE(keys_out, uint64_t, (size_t)T * 8);
+      tb = 0;
+      EGO_HIP(rocprim::radix_sort_keys(nullptr, tb, keys_in, keys_out, (size_t)T, 0u, end_bit, st));
+      EGO_TAKE(tmp2, char, tb);
+      EGO_HIP(rocprim::radix_sort_keys(tmp2, tb, keys_in, keys_out, (size_t)T, 0u, end_bit, st));
+      // (stream order: the buffers go back to the caller's stream-ordered allocator only after the work that reads
+      // them has been enqueued on the same stream)
+      mem.give(tmp2);
+      mem.give(keys_in);
+      mem.give(offs);
+      mem.give(members);
+      members = keys_in = nullptr;
+      EGO_TAKE(next, uint64_t, (size_t)T * 8);
+      tb = 0;
+      EGO_HIP(rocprim::unique(nullptr, tb, keys_out, next, count_d, (size_t)T, SameMember(), st));
+      EGO_TAKE(tmp3, char, tb);
+      EGO_HIP(rocprim::unique(tmp3, tb, keys_out, next, count_d, (size_t)T, SameMember(), st));
+      mem.give(tmp3);
+      mem.give(keys_out);
+      members = next;
+      cap = T;
     }
+    EGO_HIP(hipMemcpyAsync(&M, count_d, 8, hipMemcpyDeviceToHost, st));
+    EGO_HIP(hipStreamSynchronize(st));
   }
-  hipLaunchKernelGGL(ego_prefix_kernel, dim3((unsigned)B), dim3(kBlock), 0, st, L.visited, W, L.wprefix, L.members);
-  MP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ego_node_off_kernel, dim3(1), dim3(64), 0, st, L.members, B, L.node_off);
-  MP_LAUNCH_CHECK();
-  MP_HIP(hipMemsetAsync(L.edge_cnt, 0, (size_t)B * 8, st));
-  hipLaunchKernelGGL(ego_edges_kernel<0>, ego_grid(W, B), dim3(kBlock), 0, st, rowptr, col, W, centres, L.visited,
-                     L.wprefix, L.node_off, L.edge_off, L.edge_cnt, L.cursor, nullptr, nullptr, nullptr, nullptr);
-  MP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ego_edge_off_kernel, dim3(1), dim3(64), 0, st, L.edge_cnt, B, L.edge_off);
-  MP_LAUNCH_CHECK();
-  int64_t tot[2];
-  MP_HIP(hipMemcpyAsync(&tot[0], L.node_off + B, 8, hipMemcpyDeviceToHost, st));
-  MP_HIP(hipMemcpyAsync(&tot[1], L.edge_off + B, 8, hipMemcpyDeviceToHost, st));
-  MP_HIP(hipStreamSynchronize(st));
-  counts_host[0] = tot[0];
-  counts_host[1] = tot[1];
-  return MP_OK;
-}
 
-int mp_ego_expand_emit(const int32_t* rowptr, const int32_t* col, int64_t N, const int64_t* centres,
-                       int64_t n_centres, void* ws, size_t ws_bytes, int64_t* out_src, int64_t* out_dst,
-                       int64_t* orig_node, int32_t* ego_of_node, mp_stream_t stream) {
-  if (!rowptr || !centres || !out_src || !out_dst || !orig_node || N <= 0 || n_centres <= 0) return MP_ERR_INVALID_ARG;
-  EgoWs L;
-  ego_layout(N, n_centres, ws, &L);
-  if (!ws || ws_bytes < L.total) return MP_ERR_WORKSPACE;
-  hipStream_t st = as_stream(stream);
-  const int64_t B = n_centres, W = ceil_div(N, 32);
-  MP_HIP(hipMemsetAsync(L.cursor, 0, (size_t)B * 8, st));
-  hipLaunchKernelGGL(ego_edges_kernel<1>, ego_grid(W, B), dim3(kBlock), 0, st, rowptr, col, W, centres, L.visited,
-                     L.wprefix, L.node_off, L.edge_off, L.edge_cnt, L.cursor, out_src, out_dst, orig_node,
-                     ego_of_node);
-  MP_LAUNCH_CHECK();
+  // ---- induced edges ----
+  const bool use_filter = !whole && M >= 4096;
+  uint32_t fmask = 0;
+  uint32_t* filter = nullptr;
+  EGO_TAKE(mu, uint32_t, (size_t)M * 4);
+  if (use_filter) {
+    const unsigned fb = bits_for((uint64_t)M * 16);
+    fmask = (uint32_t)((1ull << fb) - 1ull);
+    const size_t fbytes = (size_t)((1ull << fb) / 8);
+    filter = reinterpret_cast<uint32_t*>(mem.take(fbytes));
+    if (!filter) { mem.give_all(); return MP_ERR_WORKSPACE; }
+    EGO_HIP(hipMemsetAsync(filter, 0, fbytes, st));
+  }
+  hipLaunchKernelGGL(ego_index_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, members, M, mu, filter, fmask);
+  EGO_LAUNCH_CHECK();
+  EGO_TAKE(seg, int64_t, (size_t)(B + 1) * 8);
+  hipLaunchKernelGGL(ego_seg_kernel, dim3((unsigned)ceil_div(B + 1, kBlock)), dim3(kBlock), 0, st, members, M, B, seg);
+  EGO_LAUNCH_CHECK();
+  EGO_TAKE(cnt, int32_t, (size_t)M * 4);
+  EGO_TAKE(eoff, int64_t, (size_t)(M + 1) * 8);
+  const dim3 egrid((unsigned)(ceil_div(M, kWavesPerBlock) < kNumCU * 16 ? ceil_div(M, kWavesPerBlock) : kNumCU * 16));
+  if (whole)
+    hipLaunchKernelGGL((ego_edges_kernel<0, true>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
+                       seg, filter, fmask, cnt, eoff, nullptr, nullptr, nullptr, nullptr);
+  else
+    hipLaunchKernelGGL((ego_edges_kernel<0, false>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
+                       seg, filter, fmask, cnt, eoff, nullptr, nullptr, nullptr, nullptr);
+  EGO_LAUNCH_CHECK();
+  {
+    auto cnt_it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), CountAsI64{cnt, M});
+    size_t tb = 0;
+    EGO_HIP(rocprim::exclusive_scan(nullptr, tb, cnt_it, eoff, (int64_t)0, (size_t)(M + 1), rocprim::plus<int64_t>(), st));
+    EGO_TAKE(tmp, char, tb);
+    EGO_HIP(rocprim::exclusive_scan(tmp, tb, cnt_it, eoff, (int64_t)0, (size_t)(M + 1), rocprim::plus<int64_t>(), st));
+    mem.give(tmp);
+  }
+  int64_t E = 0;
+  EGO_HIP(hipMemcpyAsync(&E, eoff + M, 8, hipMemcpyDeviceToHost, st));
+  EGO_HIP(hipStreamSynchronize(st));
+  mem.give(cnt);
+
+  // ---- outputs (the caller's, tagged) ----
+  // (one block for both rows of the COO list — PyG's edge_index [2, E] without a copy: dst = src + E)
+  int64_t* o_src = reinterpret_cast<int64_t*>(alloc((size_t)(E > 0 ? 2 * E : 2) * 8, MP_EGO_TAG_EDGES, user));
+  int64_t* o_dst = o_src ? o_src + E : nullptr;
+  int64_t* o_orig = reinterpret_cast<int64_t*>(alloc((size_t)M * 8, MP_EGO_TAG_ORIG, user));
+  int32_t* o_ego = reinterpret_cast<int32_t*>(alloc((size_t)M * 4, MP_EGO_TAG_EGO_OF, user));
+  if (!o_src || !o_dst || !o_orig || !o_ego) { mem.give_all(); return MP_ERR_WORKSPACE; }
+  if (whole)
+    hipLaunchKernelGGL((ego_edges_kernel<1, true>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
+                       seg, filter, fmask, nullptr, eoff, o_src, o_dst, o_orig, o_ego);
+  else
+    hipLaunchKernelGGL((ego_edges_kernel<1, false>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
+                       seg, filter, fmask, nullptr, eoff, o_src, o_dst, o_orig, o_ego);
+  EGO_LAUNCH_CHECK();
+  out->n_nodes = M;
+  out->n_edges = E;
+  out->src = o_src;
+  out->dst = o_dst;
+  out->orig = o_orig;
+  out->ego_of = o_ego;
+  out->candidates = cand_total;
+  out->scratch_peak_bytes = mem.peak;
+  mem.give_all();   // (stream-ordered: the emit kernel above is already enqueued)
   return MP_OK;
 }
 

@@ -706,8 +706,10 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
   constexpr int RPW = TR / NP;                // ... each producer wave RPW of its rows, requested one item ahead
 
   // The two roles run SEPARATE loops over the same item sequence (the workgroup barriers b0 / b1 / b2 pair up by
-  // count: s_barrier counts arriving waves, wherever they are in the code), so the registers of the gathers in
-  // flight and of the MFMA accumulators are never live in the same code.
+  // count: s_barrier counts arriving waves, wherever they are in the code — role_barrier(), common.h: the hardware
+  // barrier with explicit fences, not __syncthreads(), whose contract is one call site for the whole block), so the
+  // registers of the gathers in flight and of the MFMA accumulators are never live in the same code.  Per item both
+  // loops execute exactly b1 and b2 (+ b0 once with a self term); tests/test_emitted_barriers.py checks the emitted code.
   if (producer) {
     // producer state: the run of the item being gathered (rp_v: the tile's 33 row starts, lane i = row i; [es, ee): this
     // wave's entries; cvF / wvF: its first 64 indices / values; vb: its first U rows, requested BEFORE the barriers that
@@ -791,7 +793,7 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
       if (cur_tile >= 0) {
         own_rows_load(cur_tile, cur_kh);
         own_rows_store(cur_tile, 0);
-        __syncthreads();   // b0, once: the first tile initialised (the consumers pass it too)
+        role_barrier();   // b0, once: the first tile initialised (the consumers pass it too)
       }
     }
     int it = 0;
@@ -948,7 +950,7 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
         }
       }
       if (wave == 0) PC_T(1);
-      __syncthreads();   // b1: every producer run is reduced into `buf` (and the consumers are done with buf ^ 1)
+      role_barrier();   // b1: every producer run is reduced into `buf` (and the consumers are done with buf ^ 1)
       if (wave == 0) PC_T(2);
 
       if constexpr (has_s) {
@@ -962,7 +964,7 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
           if (cr >= 0) T[buf][cr][tid] += carry[w - 1][tid];
         }
       }
-      __syncthreads();   // b2: buffer `buf` complete; next_tile_s published by the consumers
+      role_barrier();   // b2: buffer `buf` complete; next_tile_s published by the consumers
       if (wave == 0) PC_T(3);
       ++it;
 
@@ -1156,12 +1158,12 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
     };
     auto sync_advance = [&]() {
       if (cw == 0) PC_T(6);
-      __syncthreads();   // b1: the consumers are done with buf ^ 1
+      role_barrier();   // b1: the consumers are done with buf ^ 1
       if (cw == 0) PC_T(7);
       // the item after `nxt` opens a new tile when `nxt` is a last half: it is drawn here and published by b2
       const bool draw = nxt_tile >= 0 && nxt_kh == KH - 1;
       if (tid == kPcThreads - 1 && draw) next_tile_s = (int)atomicAdd(tile_ctr, 1u);
-      __syncthreads();   // b2
+      role_barrier();   // b2
       prev_tile = cur_tile; prev_kh = cur_kh;
       cur_tile = nxt_tile; cur_kh = nxt_kh;
       if (nxt_tile >= 0) {
@@ -1176,7 +1178,7 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
       ++it;
     };
     if (cur_tile >= 0) {
-      if (has_s) __syncthreads();   // b0, once (the producers initialise the first tile's buffer)
+      if (has_s) role_barrier();   // b0, once (the producers initialise the first tile's buffer)
       sync_advance();
       while (prev_tile >= 0) {      // (the producers run the same number of items)
         if (cw == 0) PC_T(4);

@@ -650,7 +650,7 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
     for (int k = 0; k < NSET; ++k) fetch(k, k);
     stash(0, 0, 0);
     fetch(0, NSET);
-    __syncthreads();                                   // stage 0 holds tile 0
+    role_barrier();                                    // stage 0 holds tile 0
     for (int64_t base = 0; base < nsteps; base += NSET) {
 #pragma unroll
       for (int u = 0; u < NSET; ++u) {
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
 #elif (MP_WPC_ABL & 16)
         fetch(sidx, t + 1 + NSET);                       // (loads only: no split, no LDS stores)
 #endif
-        __syncthreads();                               // step t done
+        role_barrier();                                // step t done
       }
     }
     if (do_bias) {   // 16 threads hold partial sums of the same 8 columns: add them in row order through LDS
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
         *reinterpret_cast<f32x4*>(&red[l_row][128 * h + l_col + 4]) = f32x4{bs[h][4], bs[h][5], bs[h][6], bs[h][7]};
       }
     }
-    __syncthreads();                                   // (the MFMA waves pass it on their way to the slab stores)
+    role_barrier();                                    // (the MFMA waves pass it on their way to the slab stores)
     if (do_bias && lt < 128 * DT && d0 + lt < d) {
       const float (*red)[256] = reinterpret_cast<const float (*)[256]>(&Pimg[0][0][0][0]);
       float sacc = 0.f;
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    __syncthreads();                                   // stage 0 holds tile 0
+    role_barrier();                                    // stage 0 holds tile 0
     for (int64_t t = 0; t < nsteps; ++t) {
       const int buf = (int)(t & 1);
 #pragma unroll
@@ -718,9 +718,9 @@ __global__ __launch_bounds__(WPC_THREADS, 3) void dense_wgrad_pc_kernel(const fl
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      __syncthreads();                                 // step t done: the loaders may overwrite this stage
+      role_barrier();                                  // step t done: the loaders may overwrite this stage
     }
-    __syncthreads();                                   // (the loaders' bias reduction)
+    role_barrier();                                    // (the loaders' bias reduction)
     float* slab = slabs + c * (int64_t)F * d;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

@@ -51,22 +51,23 @@ def init_from_env(device_type=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("MP_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
-        dist.init_process_group(backend, rank=rank, world_size=world)
-        if backend == "nccl":
-            # RCCL prints a version banner to STDOUT when the first communicator is created; a caller whose stdout is
-            # a protocol (bench.py: one JSON line) must not find it there: create the communicator now, with file
-            # descriptor 1 pointing at stderr for the duration
-            import sys
-            sys.stdout.flush()
-            saved = os.dup(1)
-            try:
-                os.dup2(2, 1)
+        # gloo and RCCL print banners to STDOUT (gloo when the group forms, RCCL when the first communicator is created);
+        # a caller whose stdout is a protocol (bench.py: one JSON line) must not find them there: file descriptor 1 points
+        # at stderr while the group forms and, under RCCL, while the first collective creates the communicator
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            if backend == "nccl":
                 t = torch.zeros(1, device=torch.device("cuda", torch.cuda.current_device()))
                 dist.all_reduce(t)
                 torch.cuda.synchronize()
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     return rank, local, world
 
 

@@ -1,11 +1,14 @@
 """Ego-net batches on the GPU — graphgym/models/transform.py:11-38 (ID-GNN "Full" sampler)
-for a batch of centre nodes, through mp_ego_expand_* (csrc/ego.hip)."""
+for a batch of centre nodes, through mp_ego_expand (csrc/ego.hip)."""
 import ctypes as C
 
 import torch
 
-from ._lib import check, lib, ptr
-from .graph import CSRGraph, _require_hip, _stream
+from ._lib import ALLOC_FN, FREE_FN, EgoResult, EngineError, check, lib, ptr
+from .graph import CSRGraph, _require_hip, _stream  # noqa: F401
+
+TAG_SCRATCH, TAG_EDGES, TAG_ORIG, TAG_EGO_OF = range(4)
+last_stats = {}          # the last call's sizes (bench / tests read them): nodes, edges, candidates, scratch_peak_bytes
 
 
 def ego_batch(base, centres, radius):
@@ -14,24 +17,47 @@ def ego_batch(base, centres, radius):
 
     Returns (edge_index [2, E] int64 in PyG convention, orig_node [N'] int64, node_id_index [B] int64,
     ego_of_node [N'] int32): node k of the expanded graph is original node orig_node[k]; the centres
-    are nodes 0..B-1 (node_id_index = arange(B), transform.py:38)."""
+    are nodes 0..B-1 (node_id_index = arange(B), transform.py:38).
+
+    Work and memory follow the ego nets (members + candidate neighbours of one level at a time; nothing is sized by the
+    base graph): the engine asks for its buffers through a callback that hands out torch tensors on the current stream
+    and returns scratch to torch's cache as each level finishes.  Synchronises the current stream."""
     _require_hip(centres, "centres")
     L = lib()
     dev = base.device
     cen = centres.to(torch.int64).contiguous()
     B, N = cen.numel(), base.num_nodes
+    held, outs, failure = {}, {}, []
+
+    def _alloc(nbytes, tag, _user):
+        try:
+            t = torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=dev)
+        except Exception as e:          # (an exception must not cross the C frame: NULL -> MP_ERR_WORKSPACE)
+            failure.append(e)
+            return None
+        if tag == TAG_SCRATCH:
+            held[t.data_ptr()] = t
+        else:
+            outs[tag] = t
+        return t.data_ptr()
+
+    def _free(p, _user):
+        held.pop(p, None)
+
+    alloc_cb, free_cb = ALLOC_FN(_alloc), FREE_FN(_free)
+    res = EgoResult()
     with torch.cuda.device(dev):
-        nb = C.c_size_t(0)
-        check(L.mp_ego_ws_bytes(N, B, C.byref(nb)), "mp_ego_ws_bytes")
-        ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
-        counts = (C.c_int64 * 2)()
-        check(L.mp_ego_expand_count(ptr(base.rowptr), ptr(base.col), N, ptr(cen), B, int(radius), ptr(ws),
-                                    nb.value, counts, _stream()), "mp_ego_expand_count")
-        n_out, e_out = int(counts[0]), int(counts[1])
-        ei = torch.empty((2, max(e_out, 1)), dtype=torch.int64, device=dev)
-        orig = torch.empty(max(n_out, 1), dtype=torch.int64, device=dev)
-        ego_of = torch.empty(max(n_out, 1), dtype=torch.int32, device=dev)
-        check(L.mp_ego_expand_emit(ptr(base.rowptr), ptr(base.col), N, ptr(cen), B, ptr(ws), nb.value,
-                                   ptr(ei[0]), ptr(ei[1]), ptr(orig), ptr(ego_of), _stream()),
-              "mp_ego_expand_emit")
-    return ei[:, :e_out], orig[:n_out], torch.arange(B, device=dev), ego_of[:n_out]
+        status = L.mp_ego_expand(ptr(base.rowptr), ptr(base.col), N, ptr(cen), B, int(radius), alloc_cb, free_cb, None,
+                                 C.byref(res), _stream())
+    held.clear()
+    if status != 0 and failure:
+        raise EngineError(f"mp_ego_expand: allocation failed inside the expansion: {failure[0]!r}") from failure[0]
+    check(status, "mp_ego_expand")
+    n_out, e_out = int(res.n_nodes), int(res.n_edges)
+    ei = outs[TAG_EDGES].view(torch.int64)[:2 * e_out].view(2, e_out)      # row 0 = source, row 1 = destination
+    orig = outs[TAG_ORIG].view(torch.int64)[:n_out]
+    ego_of = outs[TAG_EGO_OF].view(torch.int32)[:n_out]
+    last_stats.clear()
+    last_stats.update(nodes=n_out, edges=e_out, candidates=int(res.candidates),
+                      scratch_peak_bytes=int(res.scratch_peak_bytes), centres=B)
+    return ei, orig, torch.arange(B, device=dev), ego_of

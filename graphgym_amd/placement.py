@@ -48,9 +48,10 @@ TRIES = int(os.environ.get("MP_PLACE_TRIES", "4"))
 EXPLORE_TRIES = int(os.environ.get("MP_PLACE_EXPLORE", "8"))   # candidates for the first read sets of a process, see below
 EXPLORE_SETS = 2
 ACCEPT = float(os.environ.get("MP_PLACE_ACCEPT", "0.05"))
+HOLD_FRAC = float(os.environ.get("MP_PLACE_HOLD_FRAC", "0.25"))   # rejected candidates held at once: at most this share of free memory
 MEMO_ENTRIES = 4096
 
-_lock = threading.Lock()
+_lock = threading.RLock()             # memo / yardsticks are also touched from the autograd thread
 _state = {}                               # device index -> {"t_min": {chunk bytes: ms}, "memo": OrderedDict, "stats": {...}}
 
 
@@ -73,6 +74,13 @@ def _probe_gather(src, src_bytes, dst, dst_bytes, reps=1):
     check(lib().mp_probe_gather_ms(C.c_void_p(src), src_bytes, C.c_void_p(dst), dst_bytes, FAN, reps, C.byref(ms),
                                    _stream()), "mp_probe_gather_ms")
     return ms.value
+
+
+def _segments_freed(device):
+    try:
+        return torch.cuda.memory_stats(device).get("segment.all.freed", 0)
+    except Exception:
+        return 0
 
 
 def enabled():
@@ -162,7 +170,13 @@ def empty_or_torch(shape, device, reads=(), dtype=torch.float32, tries=None, acc
     accept = ACCEPT if accept is None else float(accept)
     st = _dev_state(t.device)
     st["stats"]["allocations"] += 1
-    with torch.cuda.device(t.device):
+    with _lock, torch.cuda.device(t.device):
+        # a segment torch returned to the driver since the last look (empty_cache, an out-of-memory retry) may come back
+        # at the same virtual address on different physical memory: remembered probe results would be stale
+        freed = _segments_freed(t.device)
+        if freed != st.get("segments_freed"):
+            st["memo"].clear()
+            st["segments_freed"] = freed
         ms, chunk = pair_cost_ms(reads, t, st)
         if ms is None:
             return t
@@ -183,7 +197,13 @@ def empty_or_torch(shape, device, reads=(), dtype=torch.float32, tries=None, acc
             tries = max(tries, EXPLORE_TRIES)
         best, best_ms, seen = t, ms, [ms]
         held = []
+        # the search holds every rejected candidate while it allocates the next (so that torch hands out a DIFFERENT
+        # block): bounded to HOLD_FRAC of the memory free when the search starts, whatever `tries` says
+        hold_budget = int(HOLD_FRAC * torch.cuda.mem_get_info(t.device)[0])
         while len(seen) < tries:
+            if (len(held) + 1) * nbytes > hold_budget:
+                st["stats"]["hold_cap_hits"] = st["stats"].get("hold_cap_hits", 0) + 1
+                break
             spread = accept >= 0.0 and max(seen) > (1.0 + accept) * min(seen)
             if spread:
                 st["contrast"] = True
@@ -203,7 +223,21 @@ def empty_or_torch(shape, device, reads=(), dtype=torch.float32, tries=None, acc
             st["t_min"][gkey] = min(st["t_min"][gkey], ms)
             if ms < best_ms:
                 best, best_ms = t, ms
+        st["stats"]["held_bytes_peak"] = max(st["stats"].get("held_bytes_peak", 0), len(held) * nbytes)
+        n_held = len(held)
         del held, t
+        if n_held > 2 and os.environ.get("MP_PLACE_RELEASE", "1") != "0":
+            # a wide search leaves several full-size blocks in torch's cache that nothing may ever ask for again: hand the
+            # cached blocks of THIS search back to the driver.  torch offers no per-block release outside a private pool
+            # (and a pool would take the chosen block out of the cache every later step reuses), so this is
+            # empty_cache() — issued only after a search that held more than two candidates, i.e. a process's first
+            # allocations, never in the steady state of a loop (there the memo answers and nothing is held)
+            torch.cuda.empty_cache()
+            st["stats"]["cache_releases"] = st["stats"].get("cache_releases", 0) + 1
+            keep = best.data_ptr()                      # the released blocks' addresses may come back on other memory
+            for k in [k for k in st["memo"] if k[2] != keep]:
+                del st["memo"][k]
+            st["segments_freed"] = _segments_freed(best.device)
         if len(st["t_min"]) > MEMO_ENTRIES:
             st["t_min"].clear()
         tmin = st["t_min"].get(rkey, best_ms)

@@ -471,22 +471,36 @@ int mp_spmm_heads_f32(const int32_t* rowptr, const int32_t* col, const float* a,
  * for a batch of centre nodes, on the device.  The base CSR must be    *
  * symmetric (the reference's graphs are undirected nx.Graph).          *
  *   new ids: centre c -> c (0..B-1); other members of ego c -> fresh    *
- *   consecutive ids in ascending original id, egos one after another;   *
- *   radius > 4 takes the whole graph (transform.py:18-19).              *
- * Two calls: _count sizes the outputs (SYNCHRONISES), _emit fills them  *
- * from the same workspace.                                              *
+ *   consecutive ids in ascending original id, egos one after another    *
+ *   (transform.py:24-36); radius > 4 takes the whole graph (:17-18).    *
+ * Cost follows the ego nets: the work and every buffer are sized by the *
+ * members and candidate neighbours of the level at hand, nothing by N   *
+ * (rounds 1-3 kept B x N bitmaps).  Sizes are data, so the engine asks  *
+ * the CALLER for memory through a callback (e.g. torch's caching        *
+ * allocator) — scratch is handed back level by level, the four outputs  *
+ * stay with the caller.  One call; SYNCHRONISES the stream (radius + 2  *
+ * reads of counters).                                                   *
  * ------------------------------------------------------------------ */
-int mp_ego_ws_bytes(int64_t N, int64_t n_centres, size_t* bytes_host);
-/* counts_host[2] <- {total nodes of the expanded graph, total directed edges} */
-int mp_ego_expand_count(const int32_t* rowptr, const int32_t* col, int64_t N,
-                        const int64_t* centres, int64_t n_centres, int32_t radius,
-                        void* ws, size_t ws_bytes, int64_t* counts_host, mp_stream_t stream);
-/* out_src/out_dst [edges] int64 (new ids, unordered within an ego), orig_node [nodes] int64
- * (original id of every new node), ego_of_node [nodes] int32 or NULL (owning centre) */
-int mp_ego_expand_emit(const int32_t* rowptr, const int32_t* col, int64_t N,
-                       const int64_t* centres, int64_t n_centres, void* ws, size_t ws_bytes,
-                       int64_t* out_src, int64_t* out_dst, int64_t* orig_node,
-                       int32_t* ego_of_node, mp_stream_t stream);
+enum mp_ego_tag { MP_EGO_TAG_SCRATCH = 0, MP_EGO_TAG_EDGES = 1, MP_EGO_TAG_ORIG = 2, MP_EGO_TAG_EGO_OF = 3 };
+/* device memory of `bytes` bytes, 256-byte aligned, usable on the call's stream; NULL = failure (MP_ERR_WORKSPACE) */
+typedef void* (*mp_alloc_fn)(size_t bytes, int32_t tag, void* user);
+/* a MP_EGO_TAG_SCRATCH block is no longer needed (work that uses it is already enqueued on the call's stream: the
+ * allocator must be stream-ordered, as torch's is); may be NULL (scratch then lives until the caller drops it) */
+typedef void (*mp_free_fn)(void* ptr, void* user);
+typedef struct mp_ego_result {
+  int64_t n_nodes;            /* nodes of the expanded graph = sum of the ego nets' sizes                       */
+  int64_t n_edges;            /* directed edges (both directions of an undirected edge)                         */
+  int64_t* src;               /* [n_edges] new ids; ordered by (dst's ego, dst, src).  src and dst are the two rows */
+  int64_t* dst;               /* of ONE [2, n_edges] block (MP_EGO_TAG_EDGES): dst == src + n_edges                 */
+  int64_t* orig;              /* [n_nodes] original id of every new node, MP_EGO_TAG_ORIG                       */
+  int32_t* ego_of;            /* [n_nodes] owning centre (index into `centres`), MP_EGO_TAG_EGO_OF              */
+  int64_t candidates;         /* neighbour entries pushed over all levels                                       */
+  size_t scratch_peak_bytes;  /* most scratch held at once                                                      */
+} mp_ego_result_t;
+int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N,
+                  const int64_t* centres, int64_t n_centres, int32_t radius,
+                  mp_alloc_fn alloc, mp_free_fn release, void* user,
+                  mp_ego_result_t* out, mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * Host-side synthetic graph generator (bench / tests; not a device op) *

@@ -52,3 +52,25 @@ def test_two_rank_line(dev):
     per_rank = d["config"]["stored_entries_per_gpu"]
     assert d["value"] > 1.5 * per_rank / (d["ms_per_step"] * 1e-3) * 0.5
     assert abs(d["value"] - 2 * per_rank / (d["ms_per_step"] * 1e-3)) <= 0.05 * d["value"]
+
+
+def test_two_ranks_without_a_launcher_one_line_with_the_step_object(dev):
+    """the driver's command: `python bench.py --gpus 2 ...` and nothing around it.  bench.py starts its own two ranks
+    (they share this box's GPU: gloo for the collectives) and prints ONE line that carries the weak-scaling aggregate
+    AND the data-parallel training step with its gradient exchange"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(MP_DIST_BACKEND="gloo", MP_SHARE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nodes", "200000", "--steps", "3",
+                        "--warmup", "1", "--centres", "64", "--step-steps", "3"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    rf = d["roofline"]
+    assert rf["peak_all_gpus"] == 2 * 8000.0 and abs(rf["frac_all_gpus"] - rf["achieved_all_gpus"] / rf["peak_all_gpus"]) < 1e-9
+    st = d["step"]
+    assert st["n_gpus"] == 2 and st["world_size"] == 2 and st["collective_backend"] == "gloo" and st["collectives_executed"]
+    for k in ("allreduce_ms", "allreduce_exposed_ms", "lpt_imbalance", "ms_per_step", "ms_per_step_no_exchange",
+              "ms_per_step_fresh_batch"):
+        assert k in st and st[k] is not None and st[k] >= 0, k
+    assert 1.0 <= st["lpt_imbalance"] < 1.5

@@ -94,7 +94,7 @@ def _check_model_against_oracle(dev, kind, x, ei, ids, label_index, labels, f_in
     oid = ids if model.with_id else None
     l64, loss64, g64 = _oracle_tfg_gcn_model(params, x, ei, oid, label_index, labels, torch.float64, masks)
     l32, loss32, g32 = _oracle_tfg_gcn_model(params, x, ei, oid, label_index, labels, torch.float32, masks)
-    assert_close_rows(logits, l64, 1e-5, ref32=l32, what=f"{kind} logits")
+    assert_close_rows(logits, l64, 1e-5, ref32=l32, what=f"{kind} logits", deep=True)   # whole 3-layer model
     assert_close_all(loss.reshape(1), loss64.reshape(1), 1e-5, ref32=loss32.reshape(1), what=f"{kind} loss")
     for k, p in params.items():
         assert p.grad is not None, k
@@ -515,7 +515,7 @@ def test_c5_idgin_tf_model_d512_on_ego_batch_of_the_10m_graph(dev, big_graph):
     args = (x, ei_tf.cpu(), ids.cpu(), ids.cpu(), labels.cpu())
     l64, loss64, g64 = _oracle_tfg_gin_model(params, None, *args, torch.float64, masks, n_layers, True)
     l32, loss32, g32 = _oracle_tfg_gin_model(params, None, *args, torch.float32, masks, n_layers, True)
-    assert_close_rows(logits, l64, 1e-5, ref32=l32, what="idgin d=512 logits")
+    assert_close_rows(logits, l64, 1e-5, ref32=l32, what="idgin d=512 logits", deep=True)   # whole 3-layer model
     assert_close_all(loss.reshape(1), loss64.reshape(1), 1e-5, ref32=loss32.reshape(1), what="idgin d=512 loss")
     for k, p in params.items():
         assert p.grad is not None, k

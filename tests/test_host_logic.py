@@ -188,3 +188,21 @@ def test_overlapped_buckets_give_the_full_batch_gradient_gloo_world2(tmp_path):
     torch.nn.functional.cross_entropy(model(X), Y, reduction="mean").backward()
     for p, ga, gb in zip(model.parameters(), a["grads"], b["grads"]):
         assert torch.allclose(ga, p.grad, atol=1e-6) and torch.equal(ga, gb)
+
+
+def test_bench_starts_its_own_ranks_and_relays_their_exit_code():
+    """`python bench.py --gpus 2` without a launcher (the driver's command) must start two rank processes itself.  Here
+    there is no GPU, so both ranks end with bench.py's "needs a HIP device" exit — which shows that two ranks were started,
+    that the process group formed (they got past init), that the parent relayed a non-zero code and that nothing hung."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered on the GPU by tests/test_bench_gpu.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert r.stderr.count("needs a HIP device") == 2, r.stderr[-1500:]
+    assert r.stdout.strip() == ""

@@ -139,13 +139,13 @@ def test_trained_reference_weights_forward_matches_oracle(dev, name):
         assert bool(torch.isfinite(ref64).all()) and float(ref64.abs().max()) > 0
         with torch.no_grad():
             pred, _ = model(batch)
-        assert_close_rows(pred, ref64, 1e-5, ref32=ref32, what=f"{name}: eval forward, plain path")
+        assert_close_rows(pred, ref64, 1e-5, ref32=ref32, what=f"{name}: eval forward, plain path", deep=True)   # whole model: 1 linear + 3 conv + BN + l2norm + head
         # accelerate(): BatchNorm(eval) + ReLU folded into the aggregation's row flush for the gcnidconv layers
         plugin.accelerate(model)
         batch.node_feature = x0.clone()
         with torch.no_grad():
             pred2, _ = model(batch)
-        assert_close_rows(pred2, ref64, 1e-5, ref32=ref32, what=f"{name}: eval forward, folded path")
+        assert_close_rows(pred2, ref64, 1e-5, ref32=ref32, what=f"{name}: eval forward, folded path", deep=True)   # whole model: 1 linear + 3 conv + BN + l2norm + head
         # train mode after accelerate (engine BatchNorm on batch statistics) against torch's own modules in float64
         model.train()
         batch.node_feature = x0.clone()
@@ -169,4 +169,4 @@ def test_trained_reference_weights_forward_matches_oracle(dev, name):
             pooled = torch.zeros(n_graphs, h.size(1), dtype=h.dtype).index_add_(0, batch.batch.cpu()[ids], h[ids])
             return pooled @ Wp.t() + bp
         ref_tr, ref_tr32 = train_ref(torch.float64), train_ref(torch.float32)
-        assert_close_rows(pred3, ref_tr, 1e-5, ref32=ref_tr32, what=f"{name}: train-mode forward")
+        assert_close_rows(pred3, ref_tr, 1e-5, ref32=ref_tr32, what=f"{name}: train-mode forward", deep=True)   # whole model: 1 linear + 3 conv + BN + l2norm + head
