@@ -88,6 +88,7 @@ PROTOTYPES = {
     "mp_spmm_csr_heads_f32": (C.c_int, [_p, _p, _p, _i64, _p, _pi32, _i32, _p, _i64, _p, _i64, _i32, _p, _sz, _p]),
     "mp_spmm_heads_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _p]),
     "mp_ego_expand": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "mp_lpt_partition_host": (C.c_int, [_p, _i64, _i32, _p]),
     "mp_gen_ba_edges_host": (C.c_int, [_i64, _i32, C.c_uint64, _p, _p, _p]),
     "mp_gen_powerlaw_cluster_edges_host": (C.c_int, [_i64, _i32, C.c_double, C.c_uint64, _p, _p, _p]),
 }

@@ -1,76 +1,81 @@
-"""bench.py --mode step: the data-parallel training step that CONTAINS the path's one exchange.
+"""bench.py --mode step / the `step` object of the N > 1 line: the data-parallel training step that CONTAINS the path's one
+exchange, at the reference's own cadence — a NEW batch every step (graphgym/train.py:18-25,39).
 
-A global batch of ego nets (ID-GNN Full: graphgym/models/transform.py:11-38, radius 2) around `--centres` x world
-centres of one scale-free base graph is dealt to the ranks by stored entries (LPT over a degree-based cost, computed
-identically on every rank, no communication); every rank expands its own centres on its GPU, runs the three-layer
-ID-GCN model of main_zd.py:28-74 forward and backward, and the gradients are all-reduced through GradBucket — two
-buckets in backward order, each launched asynchronously from the hook of its last gradient, so the exchange overlaps
-the rest of backward — then Adam steps.  Losses are normalised by the GLOBAL number of centres and summed over ranks:
-the exact full-batch gradient (no mean of means).
+Every step a global batch of ego nets (ID-GNN Full: graphgym/models/transform.py:11-38, radius 2) around `--centres` x
+world freshly drawn centres of one scale-free base graph is dealt to the ranks by a degree-based cost every rank computes
+alike (LPT on the host, mp_lpt_partition_host: no communication); every rank expands ITS centres on its GPU, builds the
+batch's CSR / normalisation / plans / transposed operator / identity-branch operators, runs the three-layer ID-GCN
+(d = 128) or ID-GIN (d = 512) model of main_zd.py:28-74,190-243 forward and backward, and the gradients are all-reduced
+through GradBucket — two buckets in backward order, each launched asynchronously from the hook of its last gradient, so
+the exchange overlaps the rest of backward — then Adam steps.  Losses are normalised by the GLOBAL number of centres and
+summed over ranks: the exact full-batch gradient (no mean of means).
 
-The timed region is the whole step (barrier + synchronize on both sides, max over ranks).  Reported beside it: the
-exposed wait for the exchange inside the step (`allreduce_exposed_ms`), the exchange alone (`allreduce_ms`, same
-buckets, nothing else running), and the same step without the exchange (`ms_per_step_no_exchange`): the step's
-data-parallel efficiency is the ratio of the last to `ms_per_step`.
+Three cadences are timed (barrier + synchronize on both sides, max over ranks):
+  ms_per_step                      ONE batch built outside the loop and replayed (rounds 2-3's measurement: the step alone)
+  ms_per_step_fresh_batch          a new batch per step, built one step ahead on a second stream (graphgym_amd/pipeline.py)
+  ms_per_step_fresh_batch_serial   a new batch per step, built on the step's own stream (no overlap: build + step)
+and beside them the build alone (`batch_build_ms`), the exposed wait for the exchange inside the step
+(`allreduce_exposed_ms`), the exchange alone (`allreduce_ms`), the replayed step without the exchange
+(`ms_per_step_no_exchange`), and how many graph structures the timed steps had to build themselves
+(`graph_builds_inside_steps`: 0 when the pipeline prepared everything).
 """
-import json
 import time
 
+import numpy as np
 import torch
 
 
-def _ego_cost(base, centres):
+def ego_cost_table(base):
     """stored entries of a radius-2 ego net ~ sum of its members' degrees; a deterministic proxy every rank computes
-    alike: deg(c) + sum of the degrees of c's neighbours"""
-    deg = (base.rowptr[1:] - base.rowptr[:-1]).to(torch.int64)
+    alike, for EVERY node at once: cost[c] = deg(c) + sum of the degrees of c's neighbours (one pass over the CSR)"""
     rp = base.rowptr.to(torch.int64)
-    out = []
-    col = base.col.to(torch.int64)
-    for c in centres.tolist():
-        nb = col[rp[c]:rp[c + 1]]
-        out.append(int(deg[c] + deg[nb].sum()))
-    return out
+    deg = rp[1:] - rp[:-1]
+    s = torch.zeros(base.nnz + 1, dtype=torch.int64, device=base.device)
+    torch.cumsum(deg[base.col.long()], 0, out=s[1:])
+    return (deg + s[rp[1:]] - s[rp[:-1]]).cpu().numpy()
 
 
 def run(args, rank, world, dev):
     import torch.nn.functional as F
 
     import graphgym_amd as ga
-    from graphgym_amd import dist as D, graphgen, harness as H
-    from graphgym_amd.ego import ego_batch
+    from graphgym_amd import dist as D, graph as G, graphgen, harness as H, placement
+    from graphgym_amd.pipeline import EgoBatchPipeline
 
+    kind = getattr(args, "step_model", "idgcn")
     n0 = min(args.nodes, 2_000_000)
-    f_in, d, classes, radius = 128, 128, 7, 2
+    f_in, d = (128, 128) if kind == "idgcn" else (512, 512)
+    classes, radius = 7, 2
     ei = graphgen.ba_edge_index(n0, args.m, seed=12345, device=dev)          # the same base graph on every rank
     base = ga.CSRGraph.from_edge_index(ei, n0)
     del ei
-    gen = torch.Generator().manual_seed(99)
+    cost = ego_cost_table(base)
     n_global = args.centres * world
-    centres = torch.randperm(n0, generator=gen)[:n_global]
-    labels_all = torch.randint(0, classes, (n_global,), generator=gen)
-    parts = D.lpt_partition(_ego_cost(base, centres.to(dev)), world)
-    mine = torch.tensor(parts[rank], dtype=torch.int64)
-    t0 = time.perf_counter()
-    ei2, orig, ids, _ = ego_batch(base, centres[mine].to(dev), radius)
-    torch.cuda.synchronize()
-    t_ego = time.perf_counter() - t0
+    labels_host = torch.randint(0, classes, (n0,), generator=torch.Generator().manual_seed(98))
     xg = torch.Generator(device=dev).manual_seed(7)
-    x_base = torch.rand((n0, f_in), device=dev, generator=xg) * 2 - 1      # same features on every rank
-    x = x_base[orig]
-    del x_base
-    y = labels_all[mine].to(dev)
+    x_base = torch.rand((n0, f_in), device=dev, generator=xg) * 2 - 1        # same features on every rank
+
+    def sample(k):
+        """the global batch of step k and this rank's share of it: (centres [b] host, labels [b] host, imbalance)"""
+        gen = torch.Generator().manual_seed(1000 + k)
+        cen = torch.randint(0, n0, (n_global,), generator=gen)               # with replacement, like a shuffled loader's draw
+        c = cost[cen.numpy()]
+        owner = D.lpt_owners(c, world)                                       # LPT, the same on every rank
+        mine = torch.from_numpy(np.nonzero(owner == rank)[0])
+        loads = np.bincount(owner, weights=c.astype(np.float64), minlength=world)
+        return cen[mine], labels_host[cen[mine]], float(loads.max() * world / max(loads.sum(), 1.0))
+
     torch.manual_seed(11)                                                    # identical replicas
-    model = H.TfgNodeModel("idgcn", f_in, d, classes).to(dev)
+    model = H.TfgNodeModel(kind, f_in, d, classes).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=0.01)
     bucket = D.GradBucket(model.parameters(), n_buckets=2).attach()
-    batch = H.Batch()
     kern = model.kernel_parameters()
-    nnz_local = int(ei2.size(1)) + int(orig.numel())                        # stored entries incl. the self loops gcn_id adds
+    self_loops = kind == "idgcn"                                             # gcn_id adds them (TfgIDLayer.py:500-503)
 
-    def step(exchange=True):
+    def step_on(b, exchange=True):
         bucket.zero_grad()
-        logits = model([x, ei2, ids], holder=batch)
-        ce = F.cross_entropy(logits[ids], y, reduction="sum") / n_global
+        logits = model([b.x, b.edge_index, b.ids], holder=b.holder)
+        ce = F.cross_entropy(logits[b.ids], b.y, reduction="sum") / n_global
         l2 = sum((p * p).sum() / 2 for p in kern) * (5e-4 / world)          # the same on every rank: 1 / world of it each
         (ce + l2).backward()
         e0 = torch.cuda.Event(enable_timing=True)
@@ -84,24 +89,37 @@ def run(args, rank, world, dev):
         opt.step()
         return e0, e1
 
-    for _ in range(max(args.warmup, 3)):
-        step()
+    prepare = lambda inputs, holder: model.prepare(inputs, holder)
+    warm = max(args.warmup, 3)
+
+    # ---- (1) one batch, replayed: the step alone ---------------------------------------------------------------------
+    pipe = EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev)
+    cen0, lab0, imb0 = sample(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.submit(cen0, lab0)
+    b0 = pipe.get()
+    torch.cuda.synchronize()
+    t_build0 = time.perf_counter() - t0
+    for _ in range(warm):
+        step_on(b0)
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     waits = []
     for _ in range(args.steps):
-        waits.append(step())
+        waits.append(step_on(b0))
     torch.cuda.synchronize()
     D.barrier()
     dt = D.all_reduce_max(time.perf_counter() - t0, dev)
     exposed = sum(a.elapsed_time(b) for a, b in waits) / args.steps
+    nnz_replay = b0.edges + (b0.nodes if self_loops else 0)
 
     # the same step without the exchange (what N independent GPUs would do), and the exchange alone
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(exchange=False)
+        step_on(b0, exchange=False)
     torch.cuda.synchronize()
     dt_local = D.all_reduce_max(time.perf_counter() - t0, dev)
     D.barrier()
@@ -112,19 +130,83 @@ def run(args, rank, world, dev):
             bucket._reduce(flat, async_op=False) if bucket._active() else None
     torch.cuda.synchronize()
     t_ar = D.all_reduce_max((time.perf_counter() - t0) / reps, dev)
+    nodes_replay = b0.nodes
+    del b0
 
-    total_nnz = D.all_reduce_sum(nnz_local, dev)
-    total_nodes = D.all_reduce_sum(int(orig.numel()), dev)
-    max_nnz = D.all_reduce_max(nnz_local, dev)
+    # ---- (2) a fresh batch per step ------------------------------------------------------------------------------------
+    def fresh(steps, overlap, first_k):
+        p = EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev)
+        if not overlap:
+            p.side = torch.cuda.current_stream(dev)
+        nnz, nodes, builds_in_steps, imb = 0, 0, 0, []
+        c, y, _ = sample(first_k)
+        p.submit(c, y)
+        D.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for k in range(steps):
+            b = p.get()
+            before = sum(G.BUILDS.values())
+            step_on(b)
+            builds_in_steps += sum(G.BUILDS.values()) - before
+            p.done()
+            nnz += b.edges + (b.nodes if self_loops else 0)
+            nodes += b.nodes
+            if k + 1 < steps:
+                c, y, im = sample(first_k + k + 1)
+                imb.append(im)
+                p.submit(c, y)
+            del b
+        torch.cuda.synchronize()
+        D.barrier()
+        return time.perf_counter() - t_start, nnz, nodes, builds_in_steps, imb
+
+    fresh(warm, True, 10_000)                                                # new shapes: allocator and placement settle
+    place_before = placement.stats(dev)
+    dt_fresh, nnz_fresh, nodes_fresh, builds_fresh, imbs = fresh(args.steps, True, 20_000)
+    place_after = placement.stats(dev)
+    dt_fresh = D.all_reduce_max(dt_fresh, dev)
+    dt_serial, _, _, _, _ = fresh(args.steps, False, 20_000)
+    dt_serial = D.all_reduce_max(dt_serial, dev)
+
+    # the build alone (ego expansion + feature gather + CSR / norm / plans / transpose / identity operators), one stream
+    p = EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev)
+    p.side = torch.cuda.current_stream(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nb = min(args.steps, 10)
+    for k in range(nb):
+        c, y, _ = sample(30_000 + k)
+        p.submit(c, y)
+        b = p.get()
+        del b
+    torch.cuda.synchronize()
+    t_build = D.all_reduce_max((time.perf_counter() - t0) / nb, dev)
+
+    total_nnz = D.all_reduce_sum(nnz_replay, dev)
+    total_nodes = D.all_reduce_sum(nodes_replay, dev)
+    max_nnz = D.all_reduce_max(nnz_replay, dev)
+    total_nnz_fresh = D.all_reduce_sum(nnz_fresh, dev)
+    builds_fresh = D.all_reduce_sum(builds_fresh, dev)
     res = None
     if rank == 0:
         n_par = sum(p.numel() for p in model.parameters())
+        ms = dt / args.steps * 1e3
+        ms_fresh = dt_fresh / args.steps * 1e3
         res = {
             "metric": "aggregated edges/sec + achieved HBM GB/s, GCN d=256 on 100M-edge scale-free",
             "mode": "step",
-            "value": total_nnz * args.steps / dt, "unit": "edges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 3),
-            "ms_per_step": dt / args.steps * 1e3,
+            "value": total_nnz_fresh / dt_fresh, "unit": "edges/s",
+            "value_note": "stored entries of all ranks' FRESH batches per second of step time (new batch every step, built "
+                          "one step ahead on a second stream); a step is 3 forward + 3 backward aggregations over them",
+            "n_gpus": world, "steps": args.steps, "warmup": warm,
+            "ms_per_step": ms,
+            "ms_per_step_fresh_batch": ms_fresh,
+            "ms_per_step_fresh_batch_serial": dt_serial / args.steps * 1e3,
+            "fresh_over_replayed": ms_fresh / ms,
+            "batch_build_ms": t_build * 1e3, "first_batch_build_ms": t_build0 * 1e3,
+            "graph_builds_inside_steps": int(builds_fresh),
+            "placement_probes_in_fresh_steps": place_after["probed_pairs"] - place_before["probed_pairs"],
             "ms_per_step_no_exchange": dt_local / args.steps * 1e3,
             "allreduce_exposed_ms": exposed, "allreduce_ms": t_ar * 1e3,
             "allreduce_bytes": 4 * n_par, "allreduce_buckets": len(bucket.buckets),
@@ -132,18 +214,19 @@ def run(args, rank, world, dev):
             "world_size": D.dist.get_world_size() if D.dist.is_initialized() else 1,
             "collectives_executed": bool(bucket._active()),
             "step_efficiency_vs_no_exchange": dt_local / dt,
+            "lpt_imbalance": max_nnz * world / max(total_nnz, 1),
+            "cost_imbalance_fresh_mean": float(np.mean(imbs)) if imbs else imb0,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"idgcn_tf_step_ego_r{radius}_d{d}_BA_n{n0}_m{args.m}_c{args.centres}x{world}",
-                       "what": "one ID-GCN (3 x IDGCN, d = 128) training step per rank on its LPT shard of a global "
-                               "batch of radius-2 ego nets; value = stored entries of all shards per second of step time "
-                               "(a step is 3 forward + 3 backward aggregations over them)",
+            "config": {"workload": f"{kind}_tf_step_ego_r{radius}_d{d}_BA_n{n0}_m{args.m}_c{args.centres}x{world}",
+                       "what": f"one {kind} (3 layers, d = {d}, F = {f_in}) training step per rank on its share of a global "
+                               f"batch of radius-2 ego nets around {args.centres} x {world} centres drawn anew every step",
                        "centres_per_gpu": args.centres, "global_centres": n_global,
                        "batch_nodes_total": int(total_nodes), "stored_entries_total": int(total_nnz),
                        "stored_entries_max_rank": int(max_nnz),
-                       "lpt_imbalance": max_nnz * world / max(total_nnz, 1),
-                       "ego_build_ms_rank0": t_ego * 1e3, "parameters": n_par,
-                       "parallelism": f"dp{world}: ego nets sharded by stored entries (LPT), gradient all-reduce "
-                                      f"(RCCL, 2 buckets, overlapped with backward)"},
+                       "fresh_batch_nodes_mean_rank0": nodes_fresh / args.steps, "parameters": n_par,
+                       "parallelism": f"dp{world}: ego nets dealt by a degree cost (LPT), gradient "
+                                      f"all-reduce ({'RCCL' if D.dist.is_initialized() and D.dist.get_backend() == 'nccl' else 'gloo'}, "
+                                      f"2 buckets, overlapped with backward)"},
         }
     D.barrier()
     return res

@@ -27,6 +27,9 @@
 // entries whose source is an identity node.  The main kernel leaves rows that own such an entry un-activated
 // (`defer_act`), and id_fixup_kernel adds A_id Z to exactly those rows and applies the activation.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #include "vecio.h"
 #include <atomic>
 #include <limits.h>
@@ -1189,7 +1192,7 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
   }
 }
 
-constexpr int kPcSlots = 64;
+constexpr int kPcSlots = 4096;
 constexpr int kMaxDevPc = 16;
 __device__ unsigned int g_pc_tile_ctr[kPcSlots];
 
@@ -1210,20 +1213,46 @@ static int launch_fused_tiles(const FusedArgs& a, hipStream_t st) {   // one wor
   return MP_OK;
 }
 
-// the tile counter of one launch: a slot of a small device array, zeroed on the launch's stream right before it.  Slots
-// go round: two launches share one only if more than kPcSlots are in flight at once on different streams.
+// The tile counter of one launch: 4 bytes of a device array, zeroed on the launch's stream right before it.  Launches
+// on ONE stream run in order, so a stream owns one slot for its lifetime (keyed by (device, stream)); two streams never
+// share a slot, whatever the number of launches in flight (rounds 2-3 handed out 64 slots round-robin: an eager launch
+// could memset the counter of a launch on another stream — ADVICE r3).  A launch recorded into a HIP graph bakes its
+// slot into the graph, and graphs captured on one stream may later replay concurrently on different streams: every
+// captured launch gets a slot of its own that is never handed out again.  4096 slots per device; when they run out
+// (thousands of captured launches) the call fails with MP_ERR_UNSUPPORTED rather than share one.
 static int pc_counter(unsigned int** ctr, hipStream_t st) {
-  static std::atomic<unsigned> next_slot{0};
+  static std::mutex mu;
   static unsigned int* base[kMaxDevPc] = {nullptr};
+  static int next_slot[kMaxDevPc] = {0};
+  static std::map<std::pair<int, hipStream_t>, int> slot_of;
   int dev = 0;
   MP_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevPc) return MP_ERR_UNSUPPORTED;
-  if (!base[dev]) {
-    void* p = nullptr;
-    MP_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_pc_tile_ctr)));
-    base[dev] = reinterpret_cast<unsigned int*>(p);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (st != nullptr) MP_HIP(hipStreamIsCapturing(st, &cap));
+  int slot = -1;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!base[dev]) {
+      void* p = nullptr;
+      MP_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_pc_tile_ctr)));
+      base[dev] = reinterpret_cast<unsigned int*>(p);
+    }
+    if (cap == hipStreamCaptureStatusActive) {
+      if (next_slot[dev] < kPcSlots) slot = next_slot[dev]++;
+    } else {
+      auto key = std::make_pair(dev, st);
+      auto it = slot_of.find(key);
+      if (it != slot_of.end()) {
+        slot = it->second;
+      } else if (next_slot[dev] < kPcSlots) {
+        slot = next_slot[dev]++;
+        slot_of[key] = slot;
+      }
+    }
   }
-  *ctr = base[dev] + next_slot.fetch_add(1) % kPcSlots;
+  if (slot < 0) return MP_ERR_UNSUPPORTED;
+  *ctr = base[dev] + slot;
   MP_HIP(hipMemsetAsync(*ctr, 0, sizeof(unsigned int), st));
   return MP_OK;
 }

@@ -1,4 +1,5 @@
 // Status strings, error capture, and the host-side synthetic graph generator.
+#include <algorithm>
 #include "common.h"
 #include <string>
 #include <vector>
@@ -77,6 +78,28 @@ const char* mp_status_str(int status) {
 }
 
 const char* mp_last_hip_error(void) { return mp::g_last_hip_error.c_str(); }
+
+// Longest-processing-time assignment of independent units (graphs / ego nets, cost = stored entries) to ranks: units by
+// descending cost (ties: lower index first), each to the least-loaded rank (ties: lower rank) — the host logic of the
+// data-parallel sharding (graphgym_amd/dist.py: lpt_partition), here for the per-step cadence where a
+// global batch holds 10^4-10^5 units.  Deterministic: every rank computes the same owners from the same costs.
+int mp_lpt_partition_host(const int64_t* costs_host, int64_t n, int32_t world, int32_t* owner_host) {
+  if (n < 0 || world < 1 || (n > 0 && (!costs_host || !owner_host))) return MP_ERR_INVALID_ARG;
+  std::vector<int64_t> order((size_t)n);
+  for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
+  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+    return costs_host[a] != costs_host[b] ? costs_host[a] > costs_host[b] : a < b;
+  });
+  std::vector<int64_t> load((size_t)world, 0);
+  for (int64_t k = 0; k < n; ++k) {
+    int32_t best = 0;
+    for (int32_t r = 1; r < world; ++r)
+      if (load[(size_t)r] < load[(size_t)best]) best = r;
+    owner_host[order[(size_t)k]] = best;
+    load[(size_t)best] += costs_host[order[(size_t)k]];
+  }
+  return MP_OK;
+}
 
 // Barabasi-Albert by the repeated-endpoints list: a new node t draws m targets
 // uniformly from the list of all edge endpoints so far (probability ∝ degree),

@@ -15,7 +15,8 @@ import torch.distributed as dist
 
 def lpt_partition(costs, world_size):
     """Greedy longest-processing-time assignment of units (cost = stored entries) to ranks.
-    Returns a list of index lists, deterministic for equal inputs."""
+    Returns a list of index lists, deterministic for equal inputs.  (The engine's host-side mp_lpt_partition_host
+    computes the same assignment for the 10^4-10^5 units of a per-step global batch: lpt_owners.)"""
     order = sorted(range(len(costs)), key=lambda i: (-int(costs[i]), i))
     loads = [0] * world_size
     parts = [[] for _ in range(world_size)]
@@ -26,6 +27,18 @@ def lpt_partition(costs, world_size):
     for p in parts:
         p.sort()
     return parts
+
+
+def lpt_owners(costs, world_size):
+    """the same assignment as lpt_partition as an owner array (numpy int32 [n]), through the engine's host function"""
+    import ctypes as C
+    import numpy as np
+    from ._lib import check, lib
+    c = np.ascontiguousarray(np.asarray(costs), dtype=np.int64)
+    owner = np.empty(c.size, dtype=np.int32)
+    check(lib().mp_lpt_partition_host(c.ctypes.data_as(C.c_void_p), c.size, int(world_size),
+                                      owner.ctypes.data_as(C.c_void_p)), "mp_lpt_partition_host")
+    return owner
 
 
 def force_collectives():
@@ -107,7 +120,9 @@ class GradBucket:
       (no copy in or out), buckets follow reverse parameter order (the order backward produces gradients), and a
       post-accumulate hook launches a bucket's all-reduce asynchronously the moment its last gradient is written —
       the head's and the last layers' gradients travel while the first layers are still in backward.  ``finish()``
-      waits and scales.  Use ``zero_grad()`` of the bucket (the views must survive).
+      waits and scales.  Use ``zero_grad()`` of the bucket (the views must survive).  ONE backward per finish():
+      accumulating gradients over several backward passes needs the synchronous form below (in a single process,
+      where nothing is exchanged, the hooks do nothing and accumulation works as usual).
     * ``all_reduce_mean()`` / ``all_reduce_sum()``: the synchronous form for an arbitrary loop (copies p.grad in and
       out).
 
@@ -191,11 +206,15 @@ class GradBucket:
 
     def _make_hook(self, bi):
         def hook(param):
+            if not self._active():
+                return            # a single process exchanges nothing: plain gradient accumulation keeps working
             if self._left[bi] <= 0:
                 raise RuntimeError("GradBucket: a gradient arrived for a bucket whose all-reduce was already launched "
-                                   "(a second backward before finish()); call finish() / zero_grad() between steps")
+                                   "(a second backward before finish()); call finish() / zero_grad() between steps — "
+                                   "gradient accumulation over several backward passes needs the synchronous form "
+                                   "(all_reduce_mean / all_reduce_sum after the last backward)")
             self._left[bi] -= 1
-            if self._left[bi] == 0 and self._active():
+            if self._left[bi] == 0:
                 self._check_views(bi)
                 flat = self.buckets[bi][0]
                 if flat.is_cuda and dist.get_backend() != "gloo":
@@ -293,49 +312,67 @@ class RowPartition:
         return self.bounds[self.rank], self.bounds[self.rank + 1]
 
 
+def pad_rows(h_loc, max_rows):
+    """[rows, d] -> [max_rows, d], zero rows appended (equal chunks for all_gather_into_tensor)"""
+    if h_loc.size(0) == max_rows:
+        return h_loc.contiguous()
+    pad = torch.zeros((max_rows, h_loc.size(1)), dtype=h_loc.dtype, device=h_loc.device)
+    pad[:h_loc.size(0)] = h_loc
+    return pad
+
+
+def unpad_gathered(out, bounds, max_rows):
+    """[world * max_rows, d] of padded chunks -> [N, d]: chunk p contributes its first bounds[p+1] - bounds[p] rows"""
+    world = len(bounds) - 1
+    if all(bounds[p + 1] - bounds[p] == max_rows for p in range(world)):
+        return out
+    return torch.cat([out[p * max_rows: p * max_rows + bounds[p + 1] - bounds[p]] for p in range(world)], dim=0)
+
+
+def pad_chunks(full, bounds, max_rows):
+    """[N, d] -> [world, max_rows, d]: rows bounds[p]..bounds[p+1] in chunk p, zero rows behind them (equal chunks for
+    reduce_scatter_tensor)"""
+    world = len(bounds) - 1
+    inp = torch.zeros((world, max_rows, full.size(1)), dtype=full.dtype, device=full.device)
+    for p in range(world):
+        a, b = bounds[p], bounds[p + 1]
+        inp[p, :b - a] = full[a:b]
+    return inp
+
+
 def _gather_rows(part, h_loc):
-    """[rows_p, d] on every rank -> [N, d] everywhere (all-gather with padding to the widest range)"""
+    """[rows_p, d] on every rank -> [N, d] everywhere (all-gather with padding to the widest range; the index arithmetic
+    is pad_rows / unpad_gathered, tested on CPU with ragged bounds in tests/test_host_logic.py)"""
     if part.world == 1 and not (force_collectives() and dist.is_initialized()):
         return h_loc
     d = h_loc.size(1)
-    ragged = any(part.bounds[p + 1] - part.bounds[p] != part.max_rows for p in range(part.world))
-    if ragged:
-        pad = torch.zeros((part.max_rows, d), dtype=h_loc.dtype, device=h_loc.device)
-        pad[:h_loc.size(0)] = h_loc
-    else:
-        pad = h_loc.contiguous()
+    pad = pad_rows(h_loc, part.max_rows)
     if dist.get_backend() == "gloo":
         host = pad.is_cuda
-        buf = [torch.empty_like(pad.cpu() if host else pad) for _ in range(part.world)]
-        dist.all_gather(buf, pad.cpu() if host else pad)
-        out = torch.cat([buf[p][:part.bounds[p + 1] - part.bounds[p]] for p in range(part.world)], dim=0)
-        return out.to(h_loc.device)
+        src = pad.cpu() if host else pad
+        out = torch.empty((part.world * part.max_rows, d), dtype=h_loc.dtype)
+        dist.all_gather_into_tensor(out, src)
+        return unpad_gathered(out, part.bounds, part.max_rows).to(h_loc.device)
     # RCCL: one all_gather_into_tensor of equal (padded) chunks straight into the [world * max_rows, d] result
     out = torch.empty((part.world * part.max_rows, d), dtype=h_loc.dtype, device=h_loc.device)
     dist.all_gather_into_tensor(out, pad)
-    if not ragged:
-        return out
-    return torch.cat([out[p * part.max_rows: p * part.max_rows + part.bounds[p + 1] - part.bounds[p]]
-                      for p in range(part.world)], dim=0)
+    return unpad_gathered(out, part.bounds, part.max_rows)
 
 
 def _scatter_sum_rows(part, full):
-    """sum of [N, d] partials over ranks, each rank keeping its own rows (reduce-scatter)"""
+    """sum of [N, d] partials over ranks, each rank keeping its own rows (reduce-scatter; pad_chunks lays out the equal
+    chunks reduce_scatter_tensor wants)"""
     if part.world == 1 and not (force_collectives() and dist.is_initialized()):
         return full
     r0, r1 = part.rows
-    if dist.get_backend() == "gloo":             # gloo has no reduce_scatter_tensor: all-reduce (staged through the host)
-        host = full.is_cuda
-        t = full.cpu() if host else full.contiguous()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return t[r0:r1].to(full.device)
-    # RCCL: every rank receives only its own rows (1 / world of the all-reduce's traffic).  reduce_scatter_tensor
-    # wants equal chunks: rows are padded to the widest range.
     d = full.size(1)
-    inp = torch.zeros((part.world, part.max_rows, d), dtype=full.dtype, device=full.device)
-    for p in range(part.world):
-        a, b = part.bounds[p], part.bounds[p + 1]
-        inp[p, :b - a] = full[a:b]
+    if dist.get_backend() == "gloo":             # gloo has no reduce_scatter_tensor: all-reduce of the same padded layout
+        host = full.is_cuda
+        inp = pad_chunks(full.cpu() if host else full, part.bounds, part.max_rows)
+        dist.all_reduce(inp, op=dist.ReduceOp.SUM)
+        return inp[part.rank, :r1 - r0].to(full.device)
+    # RCCL: every rank receives only its own rows (1 / world of the all-reduce's traffic)
+    inp = pad_chunks(full, part.bounds, part.max_rows)
     out = torch.empty((part.max_rows, d), dtype=full.dtype, device=full.device)
     dist.reduce_scatter_tensor(out, inp.view(-1, d), op=dist.ReduceOp.SUM)
     return out[:r1 - r0]

@@ -8,6 +8,7 @@ idconv.py:165-173 with cached=False).
 
 Row r holds the in-edges of destination r; ``col`` holds source ids.
 """
+import collections
 import ctypes as C
 import itertools
 import weakref
@@ -28,6 +29,8 @@ def _require_hip(t, name):
             f"{name} must live on a HIP device: the engine has no CPU path "
             "(the CPU oracle is test infrastructure only)")
 
+
+BUILDS = collections.Counter()   # structures built so far, by kind: a step that runs on a PREPARED batch (CSRGraph.warm) adds none
 
 _HANDLES = weakref.WeakValueDictionary()     # int handle -> CSRGraph: how a graph crosses the torch.ops.mp.* boundary
 _next_handle = itertools.count(1)
@@ -107,6 +110,7 @@ class CSRGraph:
                                     ptr(col), ptr(val), ptr(eid), ptr(ws), need.value, _stream()),
                   "mp_csr_from_coo")
             nnz = int(rowptr[N].item())
+        BUILDS["csr"] += 1
         g = cls(rowptr, col[:nnz], None if val is None else val[:nnz], eid[:nnz], N, nnz, num_cols)
         return g
 
@@ -137,6 +141,7 @@ class CSRGraph:
         return cache[stamp][0]
 
     def _select_rows(self, rows):
+        BUILDS["row_subset"] += 1
         rows = rows.to(torch.int64)
         rp64 = self.rowptr.to(torch.int64)
         start = rp64.index_select(0, rows)
@@ -199,6 +204,7 @@ class CSRGraph:
                 self._plan = src.plan()       # same rowptr, same segmentation
                 return self._plan
             L = lib()
+            BUILDS["plan"] += 1
             with torch.cuda.device(self.device):
                 nb = C.c_size_t(0)
                 cfg = None if CSRGraph.PLAN_CONFIG is None else (C.c_int32 * 4)(*CSRGraph.PLAN_CONFIG)
@@ -226,6 +232,7 @@ class CSRGraph:
                 self._t = t
                 return t
             L = lib()
+            BUILDS["transpose"] += 1
             R, N, nnz, dev = self.num_nodes, self.num_cols, self.nnz, self.device
             with torch.cuda.device(dev):
                 nb = C.c_size_t(0)
@@ -256,6 +263,7 @@ class CSRGraph:
         """row of every stored entry (cached: the attention kernels stream over it)"""
         if getattr(self, "_row_ids", None) is None:
             L = lib()
+            BUILDS["row_ids"] += 1
             out = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=self.device)
             with torch.cuda.device(self.device):
                 check(L.mp_csr_row_ids(ptr(self.rowptr), self.num_nodes, self.nnz, ptr(out), _stream()))
@@ -273,6 +281,7 @@ class CSRGraph:
         gives a row to the four waves of one workgroup, so extreme hubs are sent to the plan-based kernel"""
         cached = self.__dict__.get("_max_row")
         if cached is None:
+            BUILDS["max_row"] += 1
             cached = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if self.num_nodes > 0 else 0
             self.__dict__["_max_row"] = cached
         return cached
@@ -302,10 +311,29 @@ class CSRGraph:
                                   _lib.AXIS_ROW, ptr(deg), _stream()))
         return deg
 
+    def warm(self, id_index=None, backward=True, mean=False, tiles=True):
+        """Build and cache, NOW and on the current stream, every derived structure the aggregation launches through this
+        operator ask for — longest row, segment plan, the transposed operator (+ its longest row and plan) for the
+        backward pass, the identity-branch operators — so that the step which follows enqueues its launches without a
+        single host synchronisation or build of its own (BUILDS stays put).  The batch pipeline
+        (graphgym_amd/pipeline.py) calls this on a side stream, one batch ahead of the training step."""
+        self.max_row_entries()
+        self.plan()
+        if id_index is not None:
+            br = self.id_branch(id_index)
+            br.t.max_row_entries()
+            br.t.plan()
+        if backward:
+            t = self.transpose_mean() if mean else self.transpose()
+            t.max_row_entries()
+            t.plan()
+        return self
+
     def gcn_norm(self, deg_axis="row"):
         """D^-1/2 A D^-1/2 on the stored entries (self-loops are a from_edge_index option).
         deg_axis='row': degree by destination (TfgIDLayer.py:549); 'col': by source (idconv.py:143-144)."""
         L = lib()
+        BUILDS["gcn_norm"] += 1
         N, nnz, dev = self.num_nodes, self.nnz, self.device
         if deg_axis != "row":
             # by-source degrees from the transposed CSR's row sums (deterministic), then one scaling pass
@@ -367,6 +395,7 @@ class CSRGraph:
 
     def _id_branch_build(self, id_index):
         import types
+        BUILDS["id_branch"] += 1
         dev = self.device
         ids = id_index.to(torch.int64)
         n_id, N = ids.numel(), self.num_nodes
@@ -397,6 +426,7 @@ class CSRGraph:
 
     def _mark_ids(self, id_index):
         L = lib()
+        BUILDS["id_marks"] += 1
         ids = id_index.to(torch.int64).contiguous()
         if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.num_cols):
             raise ValueError(f"id_index has entries outside [0, {self.num_cols})")

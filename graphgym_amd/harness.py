@@ -79,6 +79,22 @@ class TfgNodeModel(nn.Module):
                 out.append(p)
         return out
 
+    def prepare(self, inputs, holder):
+        """build the batch's graph structures ahead of the step (every conv layer's prepare(); layers of one model share
+        them through `holder`'s cache).  Returns False when a layer family has no prepare(): the step then builds lazily."""
+        ok = True
+        feats, edge_index = inputs[0], inputs[1]
+        rest = [inputs[2]] if self.with_id else []
+        for conv in self.convs:
+            if not hasattr(conv, "prepare"):
+                ok = False
+                continue
+            conv.prepare([feats, edge_index] + rest, holder)
+            width = getattr(conv, "units", None)
+            if width is not None and width != feats.size(1):     # later layers see the hidden width (order selection);
+                feats = torch.empty((feats.size(0), width), device="meta")      # only its shape is read
+        return ok
+
     def forward(self, inputs, holder=None):
         x, edge_index = inputs[0], inputs[1]
         id_index = inputs[2] if self.with_id else None

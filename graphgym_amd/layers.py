@@ -679,6 +679,14 @@ class IDGCN(_KerasLike):
         normed = g0.dinv[g1.row_ids().long()] * v1 * g0.dinv[g1.col.long()]
         return g1.with_values(torch.where(g1.eid < 0, torch.full_like(normed, fill), normed))
 
+    def prepare(self, inputs, holder):
+        """the per-batch graph work of call(), ahead of time (CSRGraph.warm): normalised operator, plans, transpose,
+        identity-branch operators — cached on `holder`, where call() finds them"""
+        x, edge_index, id_index, edge_weight = _unpack(inputs, self.with_id)
+        g = self._normed_graph(holder, edge_index, x.size(0), edge_weight)
+        g.warm(id_index if _pick_order(self.order, x.size(1), self.units) == "aggregate_first" else None)
+        return g
+
     def call(self, inputs, cache=None, training=None, mask=None, holder=None):
         x, edge_index, id_index, edge_weight = _unpack(inputs, self.with_id)
         self._maybe_build(x)
@@ -774,6 +782,15 @@ class IDGIN(_KerasLike):
         else:
             self.eps = eps
         self._built = True
+
+    def prepare(self, inputs, holder):
+        """the per-batch graph work of call(), ahead of time (CSRGraph.warm), cached on `holder`"""
+        x, edge_index, id_index, _ = _unpack(inputs, self.with_id)
+        g = get_graph(holder, edge_index, x.size(0), dst_row=0, loops="none")
+        g.warm()
+        if id_index is not None:
+            g.select_rows(id_index).warm()
+        return g
 
     def call(self, inputs, cache=None, training=None, mask=None, holder=None):
         x, edge_index, id_index, _ = _unpack(inputs, self.with_id)   # edge weights ignored (:150-151)

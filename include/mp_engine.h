@@ -503,6 +503,15 @@ int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N,
                   mp_ego_result_t* out, mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
+ * Host-side sharding of independent units over ranks (not a device op) *
+ * graphgym/loader.py:247-251 (a batch is a disjoint union of graphs),  *
+ * graphgym/models/transform.py:24-36 (ego nets are disjoint): units by  *
+ * descending cost, each to the least-loaded rank (LPT; ties: lower      *
+ * index / lower rank).  owner_host[i] <- rank of unit i.                *
+ * ------------------------------------------------------------------ */
+int mp_lpt_partition_host(const int64_t* costs_host, int64_t n, int32_t world, int32_t* owner_host);
+
+/* ------------------------------------------------------------------ *
  * Host-side synthetic graph generator (bench / tests; not a device op) *
  * Barabasi-Albert preferential attachment, m links per new node,      *
  * family of datasets/syn_graph.py:42.  Writes m*(n-m) undirected      *

@@ -134,6 +134,17 @@ def main():
             e3 = (o32[k].double() - ref).abs().amax(1) / sc
             print(f"{k:14s} engine {float(ee.median()):.2e} / {float(ee.quantile(0.99)):.2e} / {float(ee.max()):.2e} | "
                   f"oracle32 {float(e3.median()):.2e} / {float(e3.quantile(0.99)):.2e} / {float(e3.max()):.2e}")
+        # BatchNorm(eval) is an affine map per column, x -> (x - mean) * gain + beta with gain = gamma / sqrt(var + eps):
+        # absolute errors of its input are multiplied by the column's gain while the row's magnitude may shrink
+        print("\n## BatchNorm(eval) column gains |gamma| / sqrt(running_var + eps): median / max, and how much the row "
+              "magnitudes change through the module (median over rows of max|out row| / max|in row|)")
+        pairs = [(f"pre_mp.Layer_{i}.post_layer.0", f"pre{i}.linear", f"pre{i}.bn_relu") for i in range(n_pre)] + \
+                [(f"mp.layer{i}.post_layer.0", f"mp{i}.conv", f"mp{i}.bn_relu") for i in range(n_mp)]
+        for pre, kin, kout in pairs:
+            gain = state[pre + ".weight"].double().abs() / torch.sqrt(state[pre + ".running_var"].double() + conf["bn.eps"])
+            ratio = o64[kout].abs().amax(1) / o64[kin].abs().amax(1).clamp(min=1e-300)
+            print(f"{kout:14s} gain {float(gain.median()):.2f} / {float(gain.max()):.2f}   row magnitude out / in: median "
+                  f"{float(ratio.median()):.3f}, min {float(ratio.min()):.3f}")
         if info["task"] == "node":
             mg = o64["head.mag"][lab].amax(1)
             print(f"\n## head rows against their sum of absolute terms: engine max {float((e / mg).max()):.2e}, float32 oracle "

@@ -206,3 +206,89 @@ def test_bench_starts_its_own_ranks_and_relays_their_exit_code():
     assert r.returncode != 0
     assert r.stderr.count("needs a HIP device") == 2, r.stderr[-1500:]
     assert r.stdout.strip() == ""
+
+
+@pytest.mark.parametrize("bounds", [[0, 3, 3, 10], [0, 5, 7], [0, 4, 8, 12], [0, 1, 9, 10, 10]])
+def test_ragged_row_partition_pad_and_unpad_helpers(bounds):
+    """the index arithmetic of the row-partitioned exchange (dist._gather_rows / _scatter_sum_rows): a one-rank RCCL
+    group can never be ragged, so the padded layouts are checked here against torch.cat / slicing references"""
+    from graphgym_amd import dist as D
+    world, n, d = len(bounds) - 1, bounds[-1], 3
+    max_rows = max(bounds[p + 1] - bounds[p] for p in range(world))
+    full = torch.arange(n * d, dtype=torch.float32).view(n, d) + 1
+    # all-gather: every rank pads its rows, the concatenation of the padded chunks is un-padded to the full matrix
+    chunks = [D.pad_rows(full[bounds[p]:bounds[p + 1]], max_rows) for p in range(world)]
+    for p, c in enumerate(chunks):
+        assert c.shape == (max_rows, d) and bool((c[bounds[p + 1] - bounds[p]:] == 0).all())
+    assert torch.equal(D.unpad_gathered(torch.cat(chunks, 0), bounds, max_rows), full)
+    # reduce-scatter: chunk p of the padded layout holds rank p's rows; summing the layouts of all ranks and slicing
+    # chunk p gives rank p the sum of everybody's partial rows
+    partials = [full * (r + 1) for r in range(world)]
+    summed = sum(D.pad_chunks(x, bounds, max_rows) for x in partials)
+    want = sum(partials)
+    for p in range(world):
+        assert torch.equal(summed[p, :bounds[p + 1] - bounds[p]], want[bounds[p]:bounds[p + 1]])
+        assert bool((summed[p, bounds[p + 1] - bounds[p]:] == 0).all())
+
+
+def _ragged_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from graphgym_amd import dist as D
+    import types
+    bounds = [0, 2, 2, 9]                                      # ragged, with an empty range
+    part = types.SimpleNamespace(world=world, rank=rank, bounds=bounds, max_rows=7, rows=(bounds[rank], bounds[rank + 1]))
+    full = torch.arange(9 * 4, dtype=torch.float32).view(9, 4)
+    got = D._gather_rows(part, full[bounds[rank]:bounds[rank + 1]].clone())
+    ok = torch.equal(got, full)
+    mine = D._scatter_sum_rows(part, full * (rank + 1))
+    ok = ok and torch.equal(mine, full[bounds[rank]:bounds[rank + 1]] * 6)      # 1 + 2 + 3
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_ragged_gather_and_scatter_sum_over_gloo_world3():
+    """the same branches (padding, equal chunks, un-padding) under a real process group with THREE ranks and ragged
+    bounds — the tensor collectives gloo offers (all_gather_into_tensor; all_reduce of the padded layout)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ragged_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True), (2, True)]
+
+
+def test_engine_lpt_matches_the_python_lpt_and_balances_heavy_tails():
+    import numpy as np
+    from graphgym_amd import dist as D
+    rng = np.random.RandomState(0)
+    costs = (rng.pareto(1.5, 4096) * 100 + 10).astype(np.int64)            # heavy-tailed, like ego-net sizes
+    costs[100:110] = costs[100]                                             # ties
+    owner = D.lpt_owners(costs, 8)
+    parts = D.lpt_partition(costs.tolist(), 8)
+    for r, p in enumerate(parts):
+        assert np.array_equal(np.nonzero(owner == r)[0], np.asarray(p))     # the same assignment, tie-breaks included
+    loads = np.bincount(owner, weights=costs.astype(np.float64), minlength=8)
+    assert loads.max() / loads.mean() < 1.01
+    assert D.lpt_owners(np.zeros(0, dtype=np.int64), 4).size == 0
+
+
+def test_inactive_grad_bucket_allows_gradient_accumulation():
+    """a single process exchanges nothing: an attached bucket must not get in the way of two backward passes per step"""
+    from graphgym_amd import dist as D
+    lin = torch.nn.Linear(4, 3)
+    bucket = D.GradBucket(lin.parameters(), n_buckets=2).attach()
+    bucket.zero_grad()
+    x = torch.randn(5, 4)
+    lin(x).sum().backward()
+    lin(x).sum().backward()                                                  # accumulates into the bucket views
+    bucket.finish(1.0)
+    ref = torch.nn.Linear(4, 3)
+    ref.load_state_dict(lin.state_dict())
+    (ref(x).sum() * 2).backward()
+    assert torch.allclose(lin.weight.grad, ref.weight.grad) and torch.allclose(lin.bias.grad, ref.bias.grad)
