@@ -68,7 +68,8 @@ def cpu_baseline(g, x, seconds=8.0):
     src = g.col[e0:e0 + take].long().cpu()
     w = g.val[e0:e0 + take].cpu() if g.val is not None else None
     xc = x.cpu()
-    cores = os.cpu_count() or 1
+    from graphgym_amd import hostcpu
+    cores = hostcpu.effective_cpus()          # the CPUs this container may use (cgroup quota), not the machine's 256
     legs = []
 
     def gather_leg(threads):
@@ -113,7 +114,9 @@ def cpu_baseline(g, x, seconds=8.0):
             "sample": f"{main['edges']} of {g.nnz} stored entries of the same graph starting at its middle row {r_mid} "
                       f"(the leading rows of a hubs-first graph are its cache-friendliest), same X (fp32, d={d}), "
                       f"gather*scale -> index_add_ in 4M-edge chunks, {main['seconds']:.1f} s of CPU work",
-            "host_cores": cores, "legs": legs}
+            "host_cores": os.cpu_count(), "usable_cores": cores,
+            "cores_note": "usable_cores = min(affinity, cgroup cpu.max quota): threads beyond it are frozen by the kernel",
+            "legs": legs}
 
 
 def pmc_traffic(workload):
@@ -360,7 +363,8 @@ def launch_ranks(n, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MP_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        from graphgym_amd import hostcpu
+        env.setdefault("OMP_NUM_THREADS", str(max(1, hostcpu.effective_cpus() // n)))
         # rank 0's stdout is the protocol; the other ranks' stdout joins stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else sys.stderr, cwd=os.getcwd()))

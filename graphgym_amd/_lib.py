@@ -87,7 +87,7 @@ PROTOTYPES = {
     "mp_sddmm_grad_f32": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _p]),
     "mp_spmm_csr_heads_f32": (C.c_int, [_p, _p, _p, _i64, _p, _pi32, _i32, _p, _i64, _p, _i64, _i32, _p, _sz, _p]),
     "mp_spmm_heads_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _p]),
-    "mp_ego_expand": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "mp_ego_expand": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
     "mp_lpt_partition_host": (C.c_int, [_p, _i64, _i32, _p]),
     "mp_gen_ba_edges_host": (C.c_int, [_i64, _i32, C.c_uint64, _p, _p, _p]),
     "mp_gen_powerlaw_cluster_edges_host": (C.c_int, [_i64, _i32, C.c_double, C.c_uint64, _p, _p, _p]),
@@ -100,7 +100,8 @@ FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 
 class EgoResult(C.Structure):
     _fields_ = [("n_nodes", C.c_int64), ("n_edges", C.c_int64), ("src", C.c_void_p), ("dst", C.c_void_p),
-                ("orig", C.c_void_p), ("ego_of", C.c_void_p), ("candidates", C.c_int64),
+                ("orig", C.c_void_p), ("ego_of", C.c_void_p), ("rowptr", C.c_void_p), ("col", C.c_void_p),
+                ("eid", C.c_void_p), ("nnz", C.c_int64), ("candidates", C.c_int64),
                 ("scratch_peak_bytes", C.c_size_t)]
 
 

@@ -17,7 +17,8 @@ Three cadences are timed (barrier + synchronize on both sides, max over ranks):
 and beside them the build alone (`batch_build_ms`), the exposed wait for the exchange inside the step
 (`allreduce_exposed_ms`), the exchange alone (`allreduce_ms`), the replayed step without the exchange
 (`ms_per_step_no_exchange`), and how many graph structures the timed steps had to build themselves
-(`graph_builds_inside_steps`: 0 when the pipeline prepared everything).
+(`graph_builds_inside_steps`: 0 when the pipeline prepared everything).  All timed loops run under
+pipeline.quiet_gc(): Python's cycle collector is kept to its young generation (a full collection is 40-80 ms).
 """
 import time
 
@@ -40,7 +41,7 @@ def run(args, rank, world, dev):
 
     import graphgym_amd as ga
     from graphgym_amd import dist as D, graph as G, graphgen, harness as H, placement
-    from graphgym_amd.pipeline import EgoBatchPipeline
+    from graphgym_amd.pipeline import EgoBatchPipeline, quiet_gc
 
     kind = getattr(args, "step_model", "idgcn")
     n0 = min(args.nodes, 2_000_000)
@@ -90,10 +91,11 @@ def run(args, rank, world, dev):
         return e0, e1
 
     prepare = lambda inputs, holder: model.prepare(inputs, holder)
+    csr = "add" if self_loops else "none"        # the CSR the model's layers ask for, written by the expansion itself
     warm = max(args.warmup, 3)
 
     # ---- (1) one batch, replayed: the step alone ---------------------------------------------------------------------
-    pipe = EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev)
+    pipe = EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev, threaded=False, csr=csr)
     cen0, lab0, imb0 = sample(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -105,13 +107,15 @@ def run(args, rank, world, dev):
         step_on(b0)
     D.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    waits = []
-    for _ in range(args.steps):
-        waits.append(step_on(b0))
-    torch.cuda.synchronize()
-    D.barrier()
-    dt = D.all_reduce_max(time.perf_counter() - t0, dev)
+    with quiet_gc() as tick:
+        t0 = time.perf_counter()
+        waits = []
+        for _ in range(args.steps):
+            waits.append(step_on(b0))
+            tick()
+        torch.cuda.synchronize()
+        D.barrier()
+        dt = D.all_reduce_max(time.perf_counter() - t0, dev)
     exposed = sum(a.elapsed_time(b) for a, b in waits) / args.steps
     nnz_replay = b0.edges + (b0.nodes if self_loops else 0)
 
@@ -135,53 +139,65 @@ def run(args, rank, world, dev):
 
     # ---- (2) a fresh batch per step ------------------------------------------------------------------------------------
     def fresh(steps, overlap, first_k):
-        p = EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev)
+        p = EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev, threaded=overlap, csr=csr)
         if not overlap:
             p.side = torch.cuda.current_stream(dev)
         nnz, nodes, builds_in_steps, imb = 0, 0, 0, []
+        host = 0.0
         c, y, _ = sample(first_k)
         p.submit(c, y)
         D.barrier()
         torch.cuda.synchronize()
-        t_start = time.perf_counter()
-        for k in range(steps):
-            b = p.get()
-            before = sum(G.BUILDS.values())
-            step_on(b)
-            builds_in_steps += sum(G.BUILDS.values()) - before
-            p.done()
-            nnz += b.edges + (b.nodes if self_loops else 0)
-            nodes += b.nodes
-            if k + 1 < steps:
-                c, y, im = sample(first_k + k + 1)
-                imb.append(im)
-                p.submit(c, y)
-            del b
-        torch.cuda.synchronize()
-        D.barrier()
-        return time.perf_counter() - t_start, nnz, nodes, builds_in_steps, imb
+        with quiet_gc() as tick:
+            t_start = time.perf_counter()
+            for k in range(steps):
+                b = p.get()
+                before = G.builds_by_this_thread()
+                th = time.perf_counter()
+                step_on(b)
+                host += time.perf_counter() - th
+                builds_in_steps += G.builds_by_this_thread() - before
+                p.done()
+                nnz += b.edges + (b.nodes if self_loops else 0)
+                nodes += b.nodes
+                if k + 1 < steps:
+                    c, y, im = sample(first_k + k + 1)
+                    imb.append(im)
+                    p.submit(c, y)
+                del b
+                tick()
+            torch.cuda.synchronize()
+            D.barrier()
+            dt_loop = time.perf_counter() - t_start
+        p.close()
+        return dt_loop, nnz, nodes, builds_in_steps, imb, host / steps
 
     fresh(warm, True, 10_000)                                                # new shapes: allocator and placement settle
     place_before = placement.stats(dev)
-    dt_fresh, nnz_fresh, nodes_fresh, builds_fresh, imbs = fresh(args.steps, True, 20_000)
+    dt_fresh, nnz_fresh, nodes_fresh, builds_fresh, imbs, host_enq = fresh(args.steps, True, 20_000)
     place_after = placement.stats(dev)
     dt_fresh = D.all_reduce_max(dt_fresh, dev)
-    dt_serial, _, _, _, _ = fresh(args.steps, False, 20_000)
+    dt_serial, _, _, _, _, _ = fresh(args.steps, False, 20_000)
     dt_serial = D.all_reduce_max(dt_serial, dev)
 
     # the build alone (ego expansion + feature gather + CSR / norm / plans / transpose / identity operators), one stream
-    p = EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev)
+    p = EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev, threaded=False, csr=csr)
     p.side = torch.cuda.current_stream(dev)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
     nb = min(args.steps, 10)
-    for k in range(nb):
-        c, y, _ = sample(30_000 + k)
-        p.submit(c, y)
-        b = p.get()
-        del b
-    torch.cuda.synchronize()
-    t_build = D.all_reduce_max((time.perf_counter() - t0) / nb, dev)
+    with quiet_gc() as tick:
+        t0 = time.perf_counter()
+        for k in range(nb):
+            c, y, _ = sample(30_000 + k)
+            p.submit(c, y)
+            b = p.get()
+            if b.timing is not None and rank == 0:
+                import sys
+                print("build phases ms:", {k: round(v, 2) for k, v in b.timing.items()}, file=sys.stderr)
+            del b
+            tick()
+        torch.cuda.synchronize()
+        t_build = D.all_reduce_max((time.perf_counter() - t0) / nb, dev)
 
     total_nnz = D.all_reduce_sum(nnz_replay, dev)
     total_nodes = D.all_reduce_sum(nodes_replay, dev)
@@ -205,6 +221,7 @@ def run(args, rank, world, dev):
             "ms_per_step_fresh_batch_serial": dt_serial / args.steps * 1e3,
             "fresh_over_replayed": ms_fresh / ms,
             "batch_build_ms": t_build * 1e3, "first_batch_build_ms": t_build0 * 1e3,
+            "host_enqueue_ms_per_fresh_step": host_enq * 1e3,
             "graph_builds_inside_steps": int(builds_fresh),
             "placement_probes_in_fresh_steps": place_after["probed_pairs"] - place_before["probed_pairs"],
             "ms_per_step_no_exchange": dt_local / args.steps * 1e3,

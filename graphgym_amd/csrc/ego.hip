@@ -21,18 +21,20 @@
 //     gets B + p - c - [u > centre_c]: egos laid out one after another, fresh ids ascending with
 //     the original id (transform.py:27-33; the order of fresh ids INSIDE an ego is the iteration
 //     order of a Python set in the reference, i.e. not defined by it);
-//   * induced edges: a wave per member walks the member's neighbour list; a neighbour belongs to
-//     the ego iff its (c, u) key is in the member list — a 1-load test against a 16-bit-per-member
-//     hash filter (L2 resident) in front of a binary search inside the ego's segment.  Pass 1
-//     counts, an exclusive scan places every member's edges (ordered: by destination member, then
-//     by source — no atomics, same output every run), pass 2 emits COO in the new ids together
-//     with `orig` (new id -> original id) and `ego_of`.
+//   * induced edges: a workgroup per (ego, chunk of its members) keeps the ego's membership test
+//     in LDS (a hash filter in front of the sorted member list) and walks its members' neighbour
+//     lists, a wave per member, the next member's neighbour ids requested one member ahead.
+//     Pass 1 counts, an exclusive scan places every member's edges (ordered: by destination
+//     member, then by source — no atomics, same output every run), pass 2 emits COO in the new
+//     ids together with `orig` (new id -> original id) and `ego_of`.
 //
 // Memory: every buffer is sized by members + candidates of the level at hand; the caller's
 // allocator hands them out (mp_alloc_fn: torch's caching allocator through ctypes) and takes them
 // back as soon as a level is done.  Peak scratch is ~45 B per emitted node; nothing scales with N.
 // The host reads three counters per level (one stream synchronisation each): sizes are data.
 #include "common.h"
+
+#include <cstdlib>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -223,11 +225,208 @@ __global__ __launch_bounds__(kBlock) void ego_edges_kernel(const int32_t* __rest
   }
 }
 
-struct CountAsI64 {
+
+// ---- the induced edges of the ego nets, one workgroup per (ego, chunk of its members) -----------------------------------
+// The wave-per-member kernel above tests every neighbour against a hash filter in L2: 1.1 * 10^8 random line reads per
+// pass at 4096 centres of a 10^7-node graph (4.2 ms per pass, latency-bound: member key -> row starts -> neighbour ids ->
+// filter word, one dependent round trip each).  An ego net is small (hundreds of members): its membership test belongs
+// in LDS.  A workgroup takes up to kEgoChunk consecutive members of ONE ego and
+//   * builds the ego's membership table in LDS — original id -> position, open addressing over kEgoTable slots — when
+//     the ego has at most kEgoList members (larger egos: every stride-th member in LDS, the search ends in global memory);
+//   * loads the row starts / ends of ITS members into LDS with all gathers in flight at once;
+//   * then every wave walks members (wave w: w, w + waves, ...): the neighbour ids of the next member are requested
+//     before the current one is tested; a test is one LDS read for a non-member, two for a member.
+// Order and numbering are the wave-per-member kernel's (edges by destination member, then by source): same output.
+constexpr int kEgoChunkMax = 512;
+constexpr int kEgoList = 4096;             // LDS words for the ego's sorted member list (or, for a larger ego, a sample of it)
+constexpr int kEgoTable = 8192;            // slots of the LDS hash table (load <= 0.5)
+constexpr int kEgoBlock = 512;
+
+struct ChunkCount {   // chunks of ego c (0 for c == B: the scan's total lands there)
+  const int64_t* seg;
+  int64_t B;
+  int64_t chunk;
+  __device__ int64_t operator()(int64_t c) const {
+    return c < B ? (seg[c + 1] - seg[c] + chunk - 1) / chunk : 0;
+  }
+};
+
+__device__ __forceinline__ uint32_t ego_hash1(uint32_t u) {
+  uint32_t h = u * 0x9E3779B1u;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  return (h ^ (h >> 13)) & (uint32_t)(kEgoTable - 1);
+}
+
+// Output order: rows by NEW id (centres 0..B-1 first, then every ego's other members), inside a row by new source id —
+// the order of the engine's CSR (csr_build.hip sorts by (row, col)), so the COO list written here IS the CSR's entry
+// list and, with `csr_col` given, the CSR itself is written beside it (int32 col / eid; the scan of the per-row counts
+// is its rowptr): a batch needs no sort of its own.  The centre of an ego has the smallest id of its row but sits in
+// the middle of the ascending-original-id walk: pass 0 notes whether a row meets it (bit 31 of the count), pass 1 then
+// shifts the entries in front of it by one.  LOOPS: a self entry (r, r) per row at its sorted place — the TF path's
+// add_self_loop (sparse_adj.py:58-63) — in the CSR only (eid = -1 - r, as mp_csr_from_coo marks inserted loops); it
+// needs a base graph without explicit self loops (the caller checks).
+template <int PASS, int kEgoChunk, bool LOOPS>
+__global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int64_t* __restrict__ centres, int64_t B,
+    const uint32_t* __restrict__ mu, const int64_t* __restrict__ seg, const int64_t* __restrict__ chunk_off,
+    const int32_t* __restrict__ wg_ego, int32_t* __restrict__ cnt, const int64_t* __restrict__ eoff,
+    int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst, int64_t* __restrict__ orig,
+    int32_t* __restrict__ ego_of, int32_t* __restrict__ csr_col, int32_t* __restrict__ csr_eid) {
+  // membership of the ego in LDS: an open-addressing table original id -> position (tab[h] = position + 1, 0 = empty;
+  // keys are compared through list[]) for egos of at most kEgoList members — a miss is one LDS read, a hit two on
+  // average; a larger ego keeps every stride-th member in list[] and finishes its searches in global memory
+  __shared__ uint32_t tab[kEgoTable];
+  __shared__ uint32_t list[kEgoList];
+  __shared__ int32_t rs_l[kEgoChunk], re_l[kEgoChunk];
+  __shared__ uint32_t v_l[kEgoChunk];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int kWaves = kEgoBlock / kWave;
+  const int64_t wg = blockIdx.x;
+  if (wg >= chunk_off[B]) return;             // (the grid is an upper bound: M / chunk + B)
+  for (int i = tid; i < kEgoTable; i += kEgoBlock) tab[i] = 0u;
+  __syncthreads();
+  const int64_t c = wg_ego[wg];               // (ego_wg_kernel: the ego whose chunk range holds wg)
+  const int64_t s0 = seg[c], s1 = seg[c + 1];
+  const int S = (int)(s1 - s0);               // (members of one ego: < 2^31, the graph has fewer nodes)
+  const bool hashed = S <= kEgoList;
+  const int stride = (S + kEgoList - 1) / kEgoList;
+  const int n_s = (S + stride - 1) / stride;
+  const int64_t m0 = s0 + (wg - chunk_off[c]) * kEgoChunk;
+  const int nm = (int)((s1 - m0) < kEgoChunk ? (s1 - m0) : kEgoChunk);
+  const int64_t centre = centres[c];
+  const uint32_t* __restrict__ mu_c = mu + s0;
+  if (hashed) {
+    for (int i = tid; i < S; i += kEgoBlock) {
+      const uint32_t u = mu_c[i];
+      list[i] = u;
+      uint32_t h = ego_hash1(u);
+      while (atomicCAS(&tab[h], 0u, (uint32_t)i + 1u) != 0u) h = (h + 1u) & (uint32_t)(kEgoTable - 1);
+    }
+  } else {
+    for (int i = tid; i < n_s; i += kEgoBlock) list[i] = mu_c[(int64_t)i * stride];
+  }
+  for (int i = tid; i < nm; i += kEgoBlock) {
+    const uint32_t v = mu[m0 + i];
+    v_l[i] = v;
+    rs_l[i] = rowptr[v];
+    re_l[i] = rowptr[v + 1];
+  }
+  __syncthreads();
+  auto new_id = [&](int q, uint32_t u) -> int64_t {          // q: position inside the ego
+    if ((int64_t)u == centre) return c;
+    return B + (s0 + q) - c - ((int64_t)u > centre ? 1 : 0);
+  };
+  // position of u among the ego's members, or -1
+  auto find = [&](uint32_t u) -> int {
+    if (hashed) {
+      uint32_t h = ego_hash1(u);
+      for (;;) {
+        const uint32_t t = tab[h];
+        if (t == 0u) return -1;
+        if (list[t - 1u] == u) return (int)(t - 1u);
+        h = (h + 1u) & (uint32_t)(kEgoTable - 1);
+      }
+    }
+    int lo = 0, hi = n_s;                                     // first sample > u
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (list[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    if (lo == 0) return -1;                                   // below the ego's smallest member
+    int a = (lo - 1) * stride, b = a + stride < S ? a + stride : S;    // mu_c[a] <= u < next sample
+    while (a < b) {
+      const int mid = (a + b) >> 1;
+      if (mu_c[mid] < u) a = mid + 1; else b = mid;
+    }
+    return (a < S && mu_c[a] == u) ? a : -1;
+  };
+  // neighbour ids are requested one 64-entry batch ahead: the next batch of this member's row, or the first batch of the
+  // wave's next member
+  auto fetch = [&](int i, int j0) -> uint32_t {
+    if (i >= nm) return 0u;
+    const int j = j0 + lane;
+    return j < re_l[i] ? ((uint32_t)col[j] & 0x7fffffffu) : 0u;
+  };
+  int i = wave;
+  uint32_t u_ahead = i < nm ? fetch(i, rs_l[i]) : 0u;
+  for (; i < nm; i += kWaves) {
+    const int rs = rs_l[i], re = re_l[i];
+    const int64_t p = m0 + i;
+    const uint32_t v = v_l[i];
+    const int64_t vid = new_id((int)(p - s0), v);
+    int64_t base = 0;
+    int has_c = 0;
+    if (PASS) {
+      base = eoff[vid];
+      has_c = (cnt[vid] >> 31) & 1;
+      if (lane == 0) {
+        orig[vid] = (int64_t)v;
+        if (ego_of) ego_of[vid] = (int32_t)c;
+      }
+    }
+    int total = 0, below = 0;                 // non-centre hits so far; those with a smaller original id than v
+    bool met_c = false;
+    if (rs >= re) u_ahead = fetch(i + kWaves, i + kWaves < nm ? rs_l[i + kWaves] : 0);     // (a member without entries)
+    for (int j0 = rs; j0 < re; j0 += kWave) {
+      const uint32_t u = u_ahead;
+      u_ahead = j0 + kWave < re ? fetch(i, j0 + kWave) : fetch(i + kWaves, i + kWaves < nm ? rs_l[i + kWaves] : 0);
+      const int q = j0 + lane < re ? find(u) : -1;
+      const bool is_c = q >= 0 && (int64_t)u == centre;
+      const bool hit = q >= 0 && !is_c;
+      const unsigned long long m = __ballot(hit);
+      const unsigned long long mb = __ballot(hit && u < v);
+      met_c = met_c || __ballot(is_c) != 0ull;
+      if (PASS && (hit || is_c)) {
+        // slot in the row: the centre first, then the other sources by new id (= by original id), the row's own self
+        // entry (LOOPS) between the smaller and the larger ones; a centre's row holds only larger ones
+        const bool after_self = LOOPS && !is_c && (vid < B || u > v);   // (the centre's id is below every row's)
+        const int slot = is_c ? 0 : has_c + total + (int)__popcll(m & ((1ull << lane) - 1ull)) + (after_self ? 1 : 0);
+        const int64_t hit_id = is_c ? c : new_id(q, u);
+        const int64_t o = base + slot - (LOOPS ? vid + (after_self ? 1 : 0) : 0);      // position without the self entries
+        out_dst[o] = vid;                     // row v holds v's in-edges
+        out_src[o] = hit_id;
+        if (csr_col) {
+          csr_col[base + slot] = (int32_t)hit_id;
+          csr_eid[base + slot] = (int32_t)o;
+        }
+      }
+      total += (int)__popcll(m);
+      below += (int)__popcll(mb);
+    }
+    if (!PASS && lane == 0) cnt[vid] = (total + (met_c ? 1 : 0) + (LOOPS ? 1 : 0)) | (met_c ? (int)0x80000000 : 0);
+    if (PASS && LOOPS && csr_col && lane == 0) {
+      const int slot = vid < B ? 0 : has_c + below;
+      csr_col[base + slot] = (int32_t)vid;
+      csr_eid[base + slot] = -1 - (int32_t)vid;
+    }
+  }
+}
+
+struct CountAsI64 {   // (bit 31 of a count is the "meets its centre" flag of the chunk kernel)
   const int32_t* cnt;
   int64_t M;
-  __device__ int64_t operator()(int64_t i) const { return i < M ? (int64_t)cnt[i] : 0; }
+  __device__ int64_t operator()(int64_t i) const { return i < M ? (int64_t)(cnt[i] & 0x7fffffff) : 0; }
 };
+
+// wg_ego[w] = the ego whose chunk range holds workgroup w (last c with chunk_off[c] <= w): one thread per workgroup, once,
+// instead of a serial search at the head of every workgroup of both edge passes
+__global__ __launch_bounds__(kBlock) void ego_wg_kernel(const int64_t* __restrict__ chunk_off, int64_t B, int64_t n_wg,
+                                                        int32_t* __restrict__ wg_ego) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_wg || w >= chunk_off[B]) return;
+  int64_t lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (chunk_off[mid] <= w) lo = mid; else hi = mid;
+  }
+  wg_ego[w] = (int32_t)lo;
+}
+
+__global__ __launch_bounds__(kBlock) void ego_rowptr_kernel(const int64_t* __restrict__ eoff, int64_t n, int32_t* rowptr32) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x)
+    rowptr32[i] = (int32_t)eoff[i];
+}
 
 // ---- host side ----------------------------------------------------------------------------------------------------
 struct EgoMem {           // scratch through the caller's allocator, with the live total tracked
@@ -289,7 +488,7 @@ using namespace mp;
 extern "C" {
 
 int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N, const int64_t* centres, int64_t n_centres,
-                  int32_t radius, mp_alloc_fn alloc, mp_free_fn release, void* user, mp_ego_result_t* out,
+                  int32_t radius, int32_t flags, mp_alloc_fn alloc, mp_free_fn release, void* user, mp_ego_result_t* out,
                   mp_stream_t stream) {
   if (!rowptr || !centres || !alloc || !out || N <= 0 || n_centres <= 0 || radius < 0) return MP_ERR_INVALID_ARG;
   if (!col && radius > 0) return MP_ERR_INVALID_ARG;
@@ -370,19 +569,10 @@ int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N, const in
   }
 
   // ---- induced edges ----
-  const bool use_filter = !whole && M >= 4096;
-  uint32_t fmask = 0;
-  uint32_t* filter = nullptr;
+  const bool want_csr = (flags & MP_EGO_CSR) != 0 && !whole;
+  const bool loops = want_csr && (flags & MP_EGO_CSR_SELF_LOOPS) != 0;
   EGO_TAKE(mu, uint32_t, (size_t)M * 4);
-  if (use_filter) {
-    const unsigned fb = bits_for((uint64_t)M * 16);
-    fmask = (uint32_t)((1ull << fb) - 1ull);
-    const size_t fbytes = (size_t)((1ull << fb) / 8);
-    filter = reinterpret_cast<uint32_t*>(mem.take(fbytes));
-    if (!filter) { mem.give_all(); return MP_ERR_WORKSPACE; }
-    EGO_HIP(hipMemsetAsync(filter, 0, fbytes, st));
-  }
-  hipLaunchKernelGGL(ego_index_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, members, M, mu, filter, fmask);
+  hipLaunchKernelGGL(ego_index_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, members, M, mu, (uint32_t*)nullptr, 0u);
   EGO_LAUNCH_CHECK();
   EGO_TAKE(seg, int64_t, (size_t)(B + 1) * 8);
   hipLaunchKernelGGL(ego_seg_kernel, dim3((unsigned)ceil_div(B + 1, kBlock)), dim3(kBlock), 0, st, members, M, B, seg);
@@ -390,12 +580,38 @@ int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N, const in
   EGO_TAKE(cnt, int32_t, (size_t)M * 4);
   EGO_TAKE(eoff, int64_t, (size_t)(M + 1) * 8);
   const dim3 egrid((unsigned)(ceil_div(M, kWavesPerBlock) < kNumCU * 16 ? ceil_div(M, kWavesPerBlock) : kNumCU * 16));
+  // one workgroup per (ego, chunk of its members): chunk_off[c] = chunks of the egos before c; the grid is the bound
+  // M / chunk + B, workgroups past chunk_off[B] leave at once
+  constexpr int kChunk = 128;
+  int64_t* chunk_off = nullptr;
+  int32_t* wg_ego = nullptr;
+  const int64_t n_wg = M / kChunk + B;
+  const dim3 cgrid((unsigned)n_wg);
+  if (!whole) {
+    chunk_off = reinterpret_cast<int64_t*>(mem.take((size_t)(B + 1) * 8));
+    wg_ego = reinterpret_cast<int32_t*>(mem.take((size_t)n_wg * 4));
+    if (!chunk_off || !wg_ego) { mem.give_all(); return MP_ERR_WORKSPACE; }
+    auto ch_it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), ChunkCount{seg, B, (int64_t)kChunk});
+    size_t tb = 0;
+    EGO_HIP(rocprim::exclusive_scan(nullptr, tb, ch_it, chunk_off, (int64_t)0, (size_t)(B + 1), rocprim::plus<int64_t>(), st));
+    EGO_TAKE(tmp, char, tb);
+    EGO_HIP(rocprim::exclusive_scan(tmp, tb, ch_it, chunk_off, (int64_t)0, (size_t)(B + 1), rocprim::plus<int64_t>(), st));
+    mem.give(tmp);
+    hipLaunchKernelGGL(ego_wg_kernel, dim3((unsigned)ceil_div(n_wg, kBlock)), dim3(kBlock), 0, st, chunk_off, B, n_wg, wg_ego);
+    EGO_LAUNCH_CHECK();
+  }
+#define EGO_CHUNK_LAUNCH(PASS, LOOPS, ...) \
+  hipLaunchKernelGGL((ego_edges_chunk_kernel<PASS, kChunk, LOOPS>), cgrid, dim3(kEgoBlock), 0, st, rowptr, col, centres, B, \
+                     mu, seg, chunk_off, wg_ego, __VA_ARGS__)
   if (whole)
     hipLaunchKernelGGL((ego_edges_kernel<0, true>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
-                       seg, filter, fmask, cnt, eoff, nullptr, nullptr, nullptr, nullptr);
+                       seg, (const uint32_t*)nullptr, 0u, cnt, eoff, nullptr, nullptr, nullptr, nullptr);
+  else if (loops)
+    EGO_CHUNK_LAUNCH(0, true, cnt, eoff, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr, (int32_t*)nullptr,
+                     (int32_t*)nullptr, (int32_t*)nullptr);
   else
-    hipLaunchKernelGGL((ego_edges_kernel<0, false>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
-                       seg, filter, fmask, cnt, eoff, nullptr, nullptr, nullptr, nullptr);
+    EGO_CHUNK_LAUNCH(0, false, cnt, eoff, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr, (int32_t*)nullptr,
+                     (int32_t*)nullptr, (int32_t*)nullptr);
   EGO_LAUNCH_CHECK();
   {
     auto cnt_it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), CountAsI64{cnt, M});
@@ -405,10 +621,11 @@ int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N, const in
     EGO_HIP(rocprim::exclusive_scan(tmp, tb, cnt_it, eoff, (int64_t)0, (size_t)(M + 1), rocprim::plus<int64_t>(), st));
     mem.give(tmp);
   }
-  int64_t E = 0;
-  EGO_HIP(hipMemcpyAsync(&E, eoff + M, 8, hipMemcpyDeviceToHost, st));
+  int64_t nnz = 0;                             // entries incl. the self entries of the CSR (LOOPS)
+  EGO_HIP(hipMemcpyAsync(&nnz, eoff + M, 8, hipMemcpyDeviceToHost, st));
   EGO_HIP(hipStreamSynchronize(st));
-  mem.give(cnt);
+  const int64_t E = loops ? nnz - M : nnz;
+  if (want_csr && nnz >= INT32_MAX) { mem.give_all(); return MP_ERR_UNSUPPORTED; }
 
   // ---- outputs (the caller's, tagged) ----
   // (one block for both rows of the COO list — PyG's edge_index [2, E] without a copy: dst = src + E)
@@ -417,19 +634,34 @@ int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N, const in
   int64_t* o_orig = reinterpret_cast<int64_t*>(alloc((size_t)M * 8, MP_EGO_TAG_ORIG, user));
   int32_t* o_ego = reinterpret_cast<int32_t*>(alloc((size_t)M * 4, MP_EGO_TAG_EGO_OF, user));
   if (!o_src || !o_dst || !o_orig || !o_ego) { mem.give_all(); return MP_ERR_WORKSPACE; }
+  int32_t *o_rp = nullptr, *o_col = nullptr, *o_eid = nullptr;
+  if (want_csr) {
+    o_rp = reinterpret_cast<int32_t*>(alloc((size_t)(M + 1) * 4, MP_EGO_TAG_ROWPTR, user));
+    o_col = reinterpret_cast<int32_t*>(alloc((size_t)(nnz > 0 ? nnz : 1) * 4, MP_EGO_TAG_COL, user));
+    o_eid = reinterpret_cast<int32_t*>(alloc((size_t)(nnz > 0 ? nnz : 1) * 4, MP_EGO_TAG_EID, user));
+    if (!o_rp || !o_col || !o_eid) { mem.give_all(); return MP_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(ego_rowptr_kernel, dim3(flat_grid(M + 1)), dim3(kBlock), 0, st, eoff, M, o_rp);
+    EGO_LAUNCH_CHECK();
+  }
   if (whole)
     hipLaunchKernelGGL((ego_edges_kernel<1, true>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
-                       seg, filter, fmask, nullptr, eoff, o_src, o_dst, o_orig, o_ego);
+                       seg, (const uint32_t*)nullptr, 0u, nullptr, eoff, o_src, o_dst, o_orig, o_ego);
+  else if (loops)
+    EGO_CHUNK_LAUNCH(1, true, cnt, eoff, o_src, o_dst, o_orig, o_ego, o_col, o_eid);
   else
-    hipLaunchKernelGGL((ego_edges_kernel<1, false>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
-                       seg, filter, fmask, nullptr, eoff, o_src, o_dst, o_orig, o_ego);
+    EGO_CHUNK_LAUNCH(1, false, cnt, eoff, o_src, o_dst, o_orig, o_ego, o_col, o_eid);
   EGO_LAUNCH_CHECK();
+#undef EGO_CHUNK_LAUNCH
   out->n_nodes = M;
   out->n_edges = E;
   out->src = o_src;
   out->dst = o_dst;
   out->orig = o_orig;
   out->ego_of = o_ego;
+  out->rowptr = o_rp;
+  out->col = o_col;
+  out->eid = o_eid;
+  out->nnz = want_csr ? nnz : 0;
   out->candidates = cand_total;
   out->scratch_peak_bytes = mem.peak;
   mem.give_all();   // (stream-ordered: the emit kernel above is already enqueued)

@@ -11,6 +11,7 @@ Row r holds the in-edges of destination r; ``col`` holds source ids.
 import collections
 import ctypes as C
 import itertools
+import threading
 import weakref
 
 import torch
@@ -31,6 +32,17 @@ def _require_hip(t, name):
 
 
 BUILDS = collections.Counter()   # structures built so far, by kind: a step that runs on a PREPARED batch (CSRGraph.warm) adds none
+BUILDS_BY_THREAD = collections.Counter()     # the same by building thread (the batch pipeline builds on a worker thread)
+
+
+def _built(kind):
+    BUILDS[kind] += 1
+    BUILDS_BY_THREAD[threading.get_ident()] += 1
+
+
+def builds_by_this_thread():
+    return BUILDS_BY_THREAD[threading.get_ident()]
+
 
 _HANDLES = weakref.WeakValueDictionary()     # int handle -> CSRGraph: how a graph crosses the torch.ops.mp.* boundary
 _next_handle = itertools.count(1)
@@ -59,6 +71,7 @@ class CSRGraph:
         self._deg_cnt = None
         self.pos = None           # for a transposed graph: index into the source CSR
         self.dinv = None
+        self.symmetric = False    # pattern AND values equal their transpose (ego batches of a symmetric graph): A^T is A
 
     # ---- construction ----------------------------------------------------
     @classmethod
@@ -110,7 +123,7 @@ class CSRGraph:
                                     ptr(col), ptr(val), ptr(eid), ptr(ws), need.value, _stream()),
                   "mp_csr_from_coo")
             nnz = int(rowptr[N].item())
-        BUILDS["csr"] += 1
+        _built("csr")
         g = cls(rowptr, col[:nnz], None if val is None else val[:nnz], eid[:nnz], N, nnz, num_cols)
         return g
 
@@ -141,7 +154,7 @@ class CSRGraph:
         return cache[stamp][0]
 
     def _select_rows(self, rows):
-        BUILDS["row_subset"] += 1
+        _built("row_subset")
         rows = rows.to(torch.int64)
         rp64 = self.rowptr.to(torch.int64)
         start = rp64.index_select(0, rows)
@@ -204,7 +217,7 @@ class CSRGraph:
                 self._plan = src.plan()       # same rowptr, same segmentation
                 return self._plan
             L = lib()
-            BUILDS["plan"] += 1
+            _built("plan")
             with torch.cuda.device(self.device):
                 nb = C.c_size_t(0)
                 cfg = None if CSRGraph.PLAN_CONFIG is None else (C.c_int32 * 4)(*CSRGraph.PLAN_CONFIG)
@@ -217,13 +230,27 @@ class CSRGraph:
         return self._plan
 
     # ---- derived graphs ----------------------------------------------------
+    def has_self_loops(self):
+        """any stored entry with row == col (one device reduction + one host read, cached)"""
+        cached = self.__dict__.get("_has_loops")
+        if cached is None:
+            cached = bool((self.row_ids() == self.col).any().item()) if self.nnz else False
+            self.__dict__["_has_loops"] = cached
+        return cached
+
     def transpose(self):
         """CSR of A^T (rows = sources) with values permuted; cached.  Graphs that share a sparsity
-        pattern (with_values / gcn_norm) share one sorted transpose pattern and only permute values."""
+        pattern (with_values / gcn_norm) share one sorted transpose pattern and only permute values.
+        A graph flagged `symmetric` is its own transpose."""
+        if self.symmetric:
+            return self
+        return self._transpose_sorted()
+
+    def _transpose_sorted(self):
         if self._t is None:
             src = getattr(self, "_pattern_of", None)
             if src is not None and src is not self:
-                t0 = src.transpose()
+                t0 = src._transpose_sorted()
                 t = CSRGraph(t0.rowptr, t0.col, None if self.val is None else self.val[t0.pos.long()], None,
                              t0.num_nodes, t0.nnz, t0.num_cols)
                 t._plan = t0._plan if t0._plan is not None else None
@@ -232,7 +259,7 @@ class CSRGraph:
                 self._t = t
                 return t
             L = lib()
-            BUILDS["transpose"] += 1
+            _built("transpose")
             R, N, nnz, dev = self.num_nodes, self.num_cols, self.nnz, self.device
             with torch.cuda.device(dev):
                 nb = C.c_size_t(0)
@@ -252,7 +279,7 @@ class CSRGraph:
 
     def transpose_with(self, val):
         """transpose pattern of this graph carrying other per-entry values"""
-        t = self.transpose()
+        t = self._transpose_sorted()           # (needs t.pos: also for a symmetric pattern, whose new values need not be)
         g = CSRGraph(t.rowptr, t.col, val[t.pos.long()] if val is not None else None, None,
                      t.num_nodes, t.nnz, t.num_cols)
         g._plan = t._plan
@@ -263,7 +290,7 @@ class CSRGraph:
         """row of every stored entry (cached: the attention kernels stream over it)"""
         if getattr(self, "_row_ids", None) is None:
             L = lib()
-            BUILDS["row_ids"] += 1
+            _built("row_ids")
             out = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=self.device)
             with torch.cuda.device(self.device):
                 check(L.mp_csr_row_ids(ptr(self.rowptr), self.num_nodes, self.nnz, ptr(out), _stream()))
@@ -281,7 +308,7 @@ class CSRGraph:
         gives a row to the four waves of one workgroup, so extreme hubs are sent to the plan-based kernel"""
         cached = self.__dict__.get("_max_row")
         if cached is None:
-            BUILDS["max_row"] += 1
+            _built("max_row")
             cached = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if self.num_nodes > 0 else 0
             self.__dict__["_max_row"] = cached
         return cached
@@ -325,15 +352,16 @@ class CSRGraph:
             br.t.plan()
         if backward:
             t = self.transpose_mean() if mean else self.transpose()
-            t.max_row_entries()
-            t.plan()
+            if t is not self:
+                t.max_row_entries()
+                t.plan()
         return self
 
     def gcn_norm(self, deg_axis="row"):
         """D^-1/2 A D^-1/2 on the stored entries (self-loops are a from_edge_index option).
         deg_axis='row': degree by destination (TfgIDLayer.py:549); 'col': by source (idconv.py:143-144)."""
         L = lib()
-        BUILDS["gcn_norm"] += 1
+        _built("gcn_norm")
         N, nnz, dev = self.num_nodes, self.nnz, self.device
         if deg_axis != "row":
             # by-source degrees from the transposed CSR's row sums (deterministic), then one scaling pass
@@ -350,6 +378,8 @@ class CSRGraph:
                                       _lib.AXIS_ROW, ptr(val_out), ptr(dinv), _stream()), "mp_gcn_norm_edges")
         g = self.with_values(val_out[:nnz])
         g.dinv = dinv[:N]
+        # D^-1/2 A D^-1/2 of a symmetric operator with the row degrees (= column degrees) on both sides is symmetric
+        g.symmetric = self.symmetric
         return g
 
     def scaled(self, row_scale=None, col_scale=None):
@@ -395,7 +425,7 @@ class CSRGraph:
 
     def _id_branch_build(self, id_index):
         import types
-        BUILDS["id_branch"] += 1
+        _built("id_branch")
         dev = self.device
         ids = id_index.to(torch.int64)
         n_id, N = ids.numel(), self.num_nodes
@@ -426,7 +456,7 @@ class CSRGraph:
 
     def _mark_ids(self, id_index):
         L = lib()
-        BUILDS["id_marks"] += 1
+        _built("id_marks")
         ids = id_index.to(torch.int64).contiguous()
         if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.num_cols):
             raise ValueError(f"id_index has entries outside [0, {self.num_cols})")

@@ -68,13 +68,32 @@ def get_graph(holder, edge_index, num_nodes, *, dst_row=1, loops="none", norm=No
                 cache = None
         if cache is not None and key in cache:
             return cache[key]
-    g = CSRGraph.from_edge_index(edge_index, num_nodes, edge_weight, dst_row=dst_row, fill=fill,
-                                 **_LOOP_FLAGS[loops])
+    base_key = (dst_row, loops, None, float(fill))
+    if cache is not None and norm is not None and base_key in cache:
+        g = cache[base_key]                                   # (e.g. seeded with the batch: seed_graph_cache)
+    else:
+        g = CSRGraph.from_edge_index(edge_index, num_nodes, edge_weight, dst_row=dst_row, fill=fill,
+                                     **_LOOP_FLAGS[loops])
     if norm is not None:
-        g = g.gcn_norm(norm)
+        g = g.gcn_norm(norm if not g.symmetric else "row")    # (symmetric: degrees by row and by column coincide)
     if cache is not None:
         cache[key] = g
     return g
+
+
+def seed_graph_cache(holder, edge_index, num_nodes, g, loops):
+    """Put a CSRGraph that was built together with the batch (ego.ego_batch(csr=...): the expansion writes the batch's
+    CSR directly) where get_graph looks for it.  `loops`: "none" (the entries of edge_index) or "add" (+ one self entry
+    per node).  The graph must be symmetric and loop-free apart from the added entries, so every self-loop policy that
+    coincides on such an input and both edge_index conventions map to it."""
+    stamp = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes))
+    cache = {"stamp": stamp, "edge_index": edge_index}
+    same = ("none", "remove") if loops == "none" else ("add", "remaining", "remove_add")
+    for dst_row in (0, 1):
+        for lp in same:
+            cache[(dst_row, lp, None, 1.0)] = g
+    setattr(holder, "_mp_graph_cache", cache)
+    return cache
 
 
 def _is_relu(fn):

@@ -13,12 +13,17 @@ The loop:   pipe.submit(c0, y0)
 stream, while the main stream works through the step it already holds).
 
 Memory discipline (torch's caching allocator is per stream): everything a batch owns is allocated on the side stream and
-read by the main stream.  Batch k - 1's memory goes back to the side stream's pool when the caller lets go of it — at
-`get()` of batch k at the earliest — and may be handed out again while batch k + 1 is built, so that build's side-stream
-work first waits for the event recorded behind step k - 1 on the main stream (`done()`; the event BEFORE the last one:
-waiting for step k itself would serialise build and step), and the main stream waits for a batch's `built` event before
-its first launch.  Centres and labels arrive as HOST tensors and are uploaded on the side stream (an upload on the main
+read by the main stream.  A batch's memory may be handed out again (to a later build, on the side stream) only behind
+the event recorded after ITS step on the main stream.  The pipeline enforces that itself: it keeps a reference to every
+batch it hands out; when build k + 1 is started (after step k was enqueued) the side stream first waits for the event
+behind step k - 1 (`done()`; the event BEFORE the last one — waiting for step k itself would serialise build and step)
+and only then are the batches up to k - 1 released; batch k stays alive until build k + 2 starts, whatever the caller does
+with its own reference.  The main stream waits for a batch's `built` event before its first launch.  Centres and labels arrive as HOST tensors and are uploaded on the side stream (an upload on the main
 stream would sit behind the queued step).  No record_stream bookkeeping, no device-wide synchronisation."""
+import contextlib
+import gc
+import os
+import time
 import types
 
 import torch
@@ -33,45 +38,104 @@ class EgoBatch(types.SimpleNamespace):
 
 
 class EgoBatchPipeline:
-    def __init__(self, base, features, radius, prepare=None, device=None):
+    def __init__(self, base, features, radius, prepare=None, device=None, threaded=True, csr=None):
         """base: CSRGraph of the (symmetric) base graph; features: [N, F] node features of the base graph;
-        prepare(inputs, holder): builds the model's per-batch graph structures (e.g. TfgNodeModel.prepare)"""
+        prepare(inputs, holder): builds the model's per-batch graph structures (e.g. TfgNodeModel.prepare);
+        threaded: the build runs on a worker THREAD as well as on its own stream — the step's launches are host work too
+        (an ID-GCN step on a 2 * 10^6-node batch is ~150 launches), and one Python thread would enqueue step and build one
+        after the other; the worker spends most of its time inside ctypes / torch calls and size reads, which release the
+        interpreter lock."""
         self.base, self.features, self.radius, self.prepare = base, features, int(radius), prepare
+        self.csr = csr      # "none" | "add": let the expansion write the batch's CSR itself (ego.ego_batch(csr=...))
         self.device = device if device is not None else base.device
-        self.side = torch.cuda.Stream(device=self.device)
+        # a HIGH-PRIORITY stream: the build is many short launches separated by size reads; queued at normal priority
+        # behind the step's long HBM-bound launches every one of those reads waits for a slot (build 7.5 ms alone, ~18 ms
+        # beside a step), at high priority its launches take the next free compute units
+        lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        self.side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MP_PIPE_PRIORITY", hi)))
         self._done = [None, None]          # events behind the last two steps on the main stream
+        self._held = []                    # the batches handed out last: the pipeline keeps them alive until it is safe
         self._pending = None
         self._first = True
+        self._pool = None
+        if threaded:
+            import concurrent.futures
+            self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="mp-batch")
 
     def submit(self, centres, labels):
         """start building the batch around `centres` (LongTensor [B], HOST) with labels `labels` ([B], HOST) on the side
-        stream"""
+        stream (and, threaded, on the worker thread: submit returns at once)"""
         main = torch.cuda.current_stream(self.device)
         if self._first:
             self.side.wait_stream(main)                    # the base graph / features are ready
             self._first = False
         if self._done[0] is not None:
             self.side.wait_event(self._done[0])            # the step before last: its batch's memory may be reused now
+        # Only now may the batches before the last one die: what the side stream enqueues from here on runs behind the
+        # event of their last step.  The LAST batch handed out stays alive inside the pipeline whatever the caller does
+        # with its own reference — its step may still be running on the main stream while this build allocates (on a
+        # worker thread the build's allocations interleave with the caller's `del batch`: a block freed too early was
+        # handed to the build and overwritten under the running step — a GPU memory fault, found the hard way).
+        del self._held[:-1]
+        if self._pool is not None and self.side != main:
+            self._pending = self._pool.submit(self._build, centres, labels)
+        else:
+            self._pending = self._build(centres, labels)
+        return self._pending
+
+    def _build(self, centres, labels):
+        torch.cuda.set_device(self.device)
+        timing = {} if os.environ.get("MP_PIPE_TIMING") == "1" else None     # (study: wall time per phase, side stream drained)
+
+        def lap(name, t0):
+            if timing is None:
+                return t0
+            self.side.synchronize()
+            t1 = time.perf_counter()
+            timing[name] = (t1 - t0) * 1e3
+            return t1
+
         with torch.cuda.stream(self.side):
             from .harness import Batch
+            t = lap("wait", time.perf_counter())
             centres = centres.to(self.device, non_blocking=True)
             labels = labels.to(self.device, non_blocking=True)
-            ei, orig, ids, _ = ego_batch(self.base, centres, self.radius)
+            t = lap("upload", t)
+            g = None
+            if self.csr is not None:
+                ei, orig, ids, _, g = ego_batch(self.base, centres, self.radius, csr=self.csr)
+            else:
+                ei, orig, ids, _ = ego_batch(self.base, centres, self.radius)
+            t = lap("ego", t)
             x = self.features.index_select(0, orig)
+            t = lap("features", t)
             holder = Batch()
+            if g is not None:
+                from .layers import seed_graph_cache
+                seed_graph_cache(holder, ei, int(orig.numel()), g, self.csr)
             inputs = [x, ei, ids]
             prepared = bool(self.prepare(inputs, holder)) if self.prepare is not None else False
+            t = lap("prepare", t)
             built = torch.cuda.Event()
             built.record(self.side)
-        self._pending = EgoBatch(x=x, edge_index=ei, ids=ids, y=labels, holder=holder, built=built, prepared=prepared,
-                                 nodes=int(orig.numel()), edges=int(ei.size(1)), ego_stats=dict(_ego.last_stats))
-        return self._pending
+        return EgoBatch(x=x, edge_index=ei, ids=ids, y=labels, holder=holder, built=built, prepared=prepared,
+                        nodes=int(orig.numel()), edges=int(ei.size(1)), ego_stats=dict(_ego.last_stats), timing=timing)
 
     def get(self):
         """the submitted batch, usable on the current (main) stream"""
         b, self._pending = self._pending, None
+        if hasattr(b, "result"):
+            b = b.result()                                 # (re-raises what the worker raised)
         torch.cuda.current_stream(self.device).wait_event(b.built)
+        self._held.append(b)
         return b
+
+    def close(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        self._held.clear()
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
 
     def done(self, batch=None):
         """call right after the step of a batch has been enqueued on the main stream"""
@@ -82,3 +146,28 @@ class EgoBatchPipeline:
 
 def builds_snapshot():
     return dict(G.BUILDS)
+
+
+@contextlib.contextmanager
+def quiet_gc():
+    """Keep Python's cycle collector out of the steps.  A full collection of a torch process's heap takes 40-80 ms
+    (measured: every ~3rd batch build of a 10 ms loop carried one — scripts/pipe_probe.py), as long as four training
+    steps.  Inside this context automatic collection is off and everything alive at entry is frozen (never traversed
+    again); the loop calls the yielded `tick()` once per step, which collects the young generation only (~0.1 ms) and
+    the middle one every 16th call.  What a step leaves behind in reference cycles (autograd graphs, ctypes callbacks)
+    is reclaimed by these; tensors themselves are freed by reference counting and never wait for the collector."""
+    gc.collect()
+    gc.freeze()
+    was = gc.isenabled()
+    gc.disable()
+    n = [0]
+
+    def tick():
+        n[0] += 1
+        gc.collect(1 if n[0] % 16 == 0 else 0)
+    try:
+        yield tick
+    finally:
+        if was:
+            gc.enable()
+        gc.unfreeze()

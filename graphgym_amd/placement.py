@@ -29,7 +29,11 @@ alike can all be slow; every further candidate is held while the next is allocat
 training loop that means new buffer pairs and new probes in later steps — so the wide search is for the first
 allocations only);
 MP_PLACE_ACCEPT the accepted slow-down of the probe against the fastest probe seen (default 0.05: good positions
-measure +0-4 %, conflicting ones +6-12 %).
+measure +0-4 %, conflicting ones +6-12 %); MP_PLACE_BUDGET_MS the probe time a process may spend per device in all
+(default 250 ms — bench.py's one long-lived output takes ~40: a training loop on fresh batches meets new buffers every
+step and would otherwise probe — and synchronise — in every one of them; measured on the ID-GIN ego-batch step: 21 probes
+and +40 ms per step);
+MP_PLACE_HOLD_FRAC the share of free memory rejected candidates may hold while a search runs (default 0.25).
 """
 import collections
 import ctypes as C
@@ -48,6 +52,7 @@ TRIES = int(os.environ.get("MP_PLACE_TRIES", "4"))
 EXPLORE_TRIES = int(os.environ.get("MP_PLACE_EXPLORE", "8"))   # candidates for the first read sets of a process, see below
 EXPLORE_SETS = 2
 ACCEPT = float(os.environ.get("MP_PLACE_ACCEPT", "0.05"))
+BUDGET_MS = float(os.environ.get("MP_PLACE_BUDGET_MS", "250"))   # probe launches a process may spend per device, in all
 HOLD_FRAC = float(os.environ.get("MP_PLACE_HOLD_FRAC", "0.25"))   # rejected candidates held at once: at most this share of free memory
 MEMO_ENTRIES = 4096
 
@@ -131,6 +136,12 @@ def pair_cost_ms(reads, t, st=None):
         if acc is not None:
             memo.move_to_end(key)
             st["stats"]["memo_hits"] += 1
+        elif st["stats"]["probe_ms_total"] >= BUDGET_MS:
+            # a loop whose buffers move every step (a fresh batch per step: new sizes, new addresses) would probe —
+            # and synchronise — in every step for ever: a process checks placements until its budget of probes is
+            # spent (MP_PLACE_BUDGET_MS of probe launches in all), then takes torch's blocks as they come
+            st["stats"]["budget_refusals"] = st["stats"].get("budget_refusals", 0) + 1
+            return None, None
         else:
             acc = 0.0
             pos = _samples(t.data_ptr(), tb, chunk)
@@ -145,7 +156,8 @@ def pair_cost_ms(reads, t, st=None):
         wsum += nb
     ms = total / wsum
     st["stats"]["probed_pairs"] += cnt
-    st["stats"]["probe_ms_total"] += 4.0 * ms * cnt          # two trials, each one untimed + one timed launch
+    st["stats"]["probe_ms_total"] += 4.0 * ms * cnt          # two trials, each one untimed + one timed launch (the
+    #                                                          budget check above reads this running total)
     return ms, chunk
 
 
@@ -217,6 +229,8 @@ def empty_or_torch(shape, device, reads=(), dtype=torch.float32, tries=None, acc
             except torch.OutOfMemoryError:
                 break                                       # no room for another candidate: keep the best so far
             ms, _ = pair_cost_ms(reads, t, st)
+            if ms is None:                                  # the probe budget ran out in mid-search: keep the best so far
+                break
             st["stats"]["retries"] += 1
             seen.append(ms)
             st["t_min"][rkey] = min(st["t_min"][rkey], ms)

@@ -481,7 +481,14 @@ int mp_spmm_heads_f32(const int32_t* rowptr, const int32_t* col, const float* a,
  * stay with the caller.  One call; SYNCHRONISES the stream (radius + 2  *
  * reads of counters).                                                   *
  * ------------------------------------------------------------------ */
-enum mp_ego_tag { MP_EGO_TAG_SCRATCH = 0, MP_EGO_TAG_EDGES = 1, MP_EGO_TAG_ORIG = 2, MP_EGO_TAG_EGO_OF = 3 };
+enum mp_ego_tag { MP_EGO_TAG_SCRATCH = 0, MP_EGO_TAG_EDGES = 1, MP_EGO_TAG_ORIG = 2, MP_EGO_TAG_EGO_OF = 3,
+                  MP_EGO_TAG_ROWPTR = 4, MP_EGO_TAG_COL = 5, MP_EGO_TAG_EID = 6 };
+/* flags of mp_ego_expand.  The edge list always comes out in the engine's CSR order (rows = destinations by new id,
+ * inside a row by new source id), so MP_EGO_CSR can hand back the batch's CSR itself — rowptr / col / eid as
+ * mp_csr_from_coo would build them from that list, without the sort.  MP_EGO_CSR_SELF_LOOPS adds one self entry per row
+ * to the CSR at its sorted place (eid = -1 - row: mp_csr_from_coo's MP_COO_ADD_SELF_LOOPS on a loop-free input; the
+ * base graph must hold no explicit self loops).  Both are ignored when radius > 4. */
+enum mp_ego_flags { MP_EGO_CSR = 1, MP_EGO_CSR_SELF_LOOPS = 2 };
 /* device memory of `bytes` bytes, 256-byte aligned, usable on the call's stream; NULL = failure (MP_ERR_WORKSPACE) */
 typedef void* (*mp_alloc_fn)(size_t bytes, int32_t tag, void* user);
 /* a MP_EGO_TAG_SCRATCH block is no longer needed (work that uses it is already enqueued on the call's stream: the
@@ -490,15 +497,19 @@ typedef void (*mp_free_fn)(void* ptr, void* user);
 typedef struct mp_ego_result {
   int64_t n_nodes;            /* nodes of the expanded graph = sum of the ego nets' sizes                       */
   int64_t n_edges;            /* directed edges (both directions of an undirected edge)                         */
-  int64_t* src;               /* [n_edges] new ids; ordered by (dst's ego, dst, src).  src and dst are the two rows */
+  int64_t* src;               /* [n_edges] new ids; ordered by (dst, src) in the new ids.  src and dst are the two rows */
   int64_t* dst;               /* of ONE [2, n_edges] block (MP_EGO_TAG_EDGES): dst == src + n_edges                 */
   int64_t* orig;              /* [n_nodes] original id of every new node, MP_EGO_TAG_ORIG                       */
   int32_t* ego_of;            /* [n_nodes] owning centre (index into `centres`), MP_EGO_TAG_EGO_OF              */
+  int32_t* rowptr;            /* MP_EGO_CSR: [n_nodes + 1], MP_EGO_TAG_ROWPTR (else NULL)                       */
+  int32_t* col;               /* MP_EGO_CSR: [nnz] source ids, MP_EGO_TAG_COL                                   */
+  int32_t* eid;               /* MP_EGO_CSR: [nnz] position in the edge list, -1 - row for a self entry, TAG_EID */
+  int64_t nnz;                /* MP_EGO_CSR: n_edges (+ n_nodes with MP_EGO_CSR_SELF_LOOPS), else 0              */
   int64_t candidates;         /* neighbour entries pushed over all levels                                       */
   size_t scratch_peak_bytes;  /* most scratch held at once                                                      */
 } mp_ego_result_t;
 int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N,
-                  const int64_t* centres, int64_t n_centres, int32_t radius,
+                  const int64_t* centres, int64_t n_centres, int32_t radius, int32_t flags,
                   mp_alloc_fn alloc, mp_free_fn release, void* user,
                   mp_ego_result_t* out, mp_stream_t stream);
 

@@ -96,3 +96,41 @@ def test_subset_of_centres_on_a_large_graph(dev):
         rest = o[o != cen[k].item()] if k < 5 else o
         fresh = orig[5:][(ego_of[5:] == k)].cpu()
         assert torch.equal(fresh, torch.sort(fresh).values)
+
+
+@pytest.mark.parametrize("radius", [1, 2, 3])
+@pytest.mark.parametrize("loops", ["none", "add"])
+def test_csr_written_by_the_expansion_equals_the_csr_built_from_its_edge_list(dev, radius, loops):
+    """ego_batch(csr=...) hands back the batch's CSRGraph written by the expansion itself; it must be, entry for entry,
+    what CSRGraph.from_edge_index builds from the returned edge_index (rowptr, col, eid) — with and without the added
+    self loops — and its GCN normalisation and aggregation must give the same numbers"""
+    import graphgym_amd as ga
+    from graphgym_amd import graphgen, ops
+    from graphgym_amd.ego import ego_batch
+    n = 20_000
+    ei0 = graphgen.ba_edge_index(n, 4, seed=radius, device=dev)
+    base = ga.CSRGraph.from_edge_index(ei0, n)
+    gen = torch.Generator().manual_seed(5)
+    cen = torch.randint(0, n, (300,), generator=gen).to(dev)
+    cen[:3] = torch.tensor([0, 1, 2], device=dev)                     # hub-centred egos (larger than the LDS table)
+    ei, orig, ids, ego_of, g = ego_batch(base, cen, radius, csr=loops)
+    assert g is not None and g.symmetric
+    n2 = orig.numel()
+    for dst_row in (0, 1):
+        want = ga.CSRGraph.from_edge_index(ei, n2, dst_row=dst_row, add_self_loops=(loops == "add"))
+        assert g.nnz == want.nnz and g.num_nodes == want.num_nodes
+        assert torch.equal(g.rowptr, want.rowptr)
+        assert torch.equal(g.col, want.col)
+        if dst_row == 1:
+            assert torch.equal(g.eid, want.eid)                       # positions in edge_index; -1 - row for added loops
+    gn, wn = g.gcn_norm("row"), want.gcn_norm("row")
+    assert torch.equal(gn.val, wn.val) and gn.symmetric
+    x = torch.rand(n2, 64, device=dev)
+    assert torch.equal(ops.spmm(gn, x, "sum"), ops.spmm(wn, x, "sum"))
+    # its transpose is itself: the same numbers as the sorted transpose of the reference build
+    assert gn.transpose() is gn
+    assert torch.allclose(ops.spmm(gn.transpose(), x, "sum"), ops.spmm(wn.transpose(), x, "sum"), rtol=1e-6, atol=1e-6)
+    # the 4-tuple form is unchanged, and a base graph with an explicit self loop falls back (fifth value None)
+    assert len(ego_batch(base, cen, radius)) == 4
+    loopy = ga.CSRGraph.from_edge_index(torch.cat([ei0, torch.tensor([[7], [7]], device=dev)], 1), n)
+    assert ego_batch(loopy, cen[:5], radius, csr=loops)[4] is None
