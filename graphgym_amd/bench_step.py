@@ -172,7 +172,13 @@ def run(args, rank, world, dev):
         p.close()
         return dt_loop, nnz, nodes, builds_in_steps, imb, host / steps
 
-    fresh(warm, True, 10_000)                                                # new shapes: allocator and placement settle
+    # new shapes every step: the allocator settles, and placement spends its per-process probe budget (placement.py:
+    # MP_PLACE_BUDGET_MS) — the warm-up runs until it is spent, the timed loop is the steady state
+    for rep in range(4):
+        spent = placement.stats(dev)["probe_ms_total"]
+        fresh(warm, True, 10_000 + 100 * rep)
+        if placement.stats(dev)["probe_ms_total"] == spent:
+            break
     place_before = placement.stats(dev)
     dt_fresh, nnz_fresh, nodes_fresh, builds_fresh, imbs, host_enq = fresh(args.steps, True, 20_000)
     place_after = placement.stats(dev)

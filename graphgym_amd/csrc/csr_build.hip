@@ -145,23 +145,61 @@ __device__ __forceinline__ int row_of_entry(const int32_t* __restrict__ rowptr, 
   return lo;
 }
 
+// Rows of CONSECUTIVE entries, a workgroup at a time.  One global binary search per entry (24 dependent loads at 10^7
+// rows) made row_ids run at 0.4 TB/s and the transpose's key pass at 1 TB/s (profiles/r03_kernel_table.md).  A tile of
+// kRowTile consecutive entries spans few rows: two searches per TILE find its first and last row, the row starts in
+// between are staged in LDS (coalesced), and every entry finds its row among them in LDS.  A tile that spans more rows
+// than the stage holds (long runs of empty rows) searches the global array between the tile's two rows instead.
+constexpr int kRowTile = 2048;
+
+template <class Body>   // body(entry, row)
+__device__ __forceinline__ void for_entries_with_rows(const int32_t* __restrict__ rowptr, int32_t N, int64_t nnz, Body body) {
+  __shared__ int32_t rp_s[kRowTile + 2];
+  __shared__ int32_t lim_s[2];
+  const int64_t n_tiles = (nnz + kRowTile - 1) / kRowTile;
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int64_t e0 = t * kRowTile;
+    const int64_t e1 = e0 + kRowTile < nnz ? e0 + kRowTile : nnz;
+    if (threadIdx.x < 2) lim_s[threadIdx.x] = row_of_entry(rowptr, N, (int32_t)(threadIdx.x == 0 ? e0 : e1 - 1));
+    __syncthreads();
+    const int r_lo = lim_s[0], r_hi = lim_s[1];
+    const int R = r_hi - r_lo + 1;                       // rows the tile touches: starts rowptr[r_lo .. r_hi]
+    const bool staged = R <= kRowTile + 1;
+    if (staged)
+      for (int i = threadIdx.x; i < R; i += kBlock) rp_s[i] = rowptr[r_lo + i];
+    __syncthreads();
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += kBlock) {
+      int lo = 0, hi = R;                                // invariant: start[lo] <= e < start[hi] (start[R] = +inf)
+      if (staged) {
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (rp_s[mid] <= (int32_t)e) lo = mid; else hi = mid;
+        }
+      } else {
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (rowptr[r_lo + mid] <= (int32_t)e) lo = mid; else hi = mid;
+        }
+      }
+      body(e, r_lo + lo);
+    }
+    __syncthreads();                                     // the stage is rewritten by the next tile
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void row_ids_kernel(const int32_t* __restrict__ rowptr, int32_t N,
                                                          int64_t nnz, int32_t* row_of) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz;
-       e += (int64_t)gridDim.x * blockDim.x)
-    row_of[e] = row_of_entry(rowptr, N, (int32_t)e);
+  for_entries_with_rows(rowptr, N, nnz, [&](int64_t e, int r) { row_of[e] = r; });
 }
 
 __global__ __launch_bounds__(kBlock) void transpose_keys_kernel(const int32_t* __restrict__ rowptr,
                                                                 const int32_t* __restrict__ col,
                                                                 int32_t N, int64_t nnz, uint64_t* keys,
                                                                 uint32_t* pay) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int r = row_of_entry(rowptr, N, (int32_t)e);
+  for_entries_with_rows(rowptr, N, nnz, [&](int64_t e, int r) {
     keys[e] = ((uint64_t)(uint32_t)col[e] << 32) | (uint64_t)(uint32_t)r;
     pay[e] = (uint32_t)e;
-  }
+  });
 }
 
 __global__ __launch_bounds__(kBlock) void transpose_emit_kernel(const uint64_t* __restrict__ keys,
@@ -378,7 +416,7 @@ int mp_check_edge_index(const int64_t* dst, const int64_t* src, int64_t E, int64
 int mp_csr_row_ids(const int32_t* rowptr, int64_t N, int64_t nnz, int32_t* row_of, mp_stream_t stream) {
   if (!rowptr || N < 0 || nnz < 0 || (nnz > 0 && !row_of)) return MP_ERR_INVALID_ARG;
   if (nnz == 0) return MP_OK;
-  hipLaunchKernelGGL(row_ids_kernel, dim3(flat_grid(nnz)), dim3(kBlock), 0, as_stream(stream), rowptr,
+  hipLaunchKernelGGL(row_ids_kernel, dim3(flat_grid(ceil_div(nnz, kRowTile) * kBlock)), dim3(kBlock), 0, as_stream(stream), rowptr,
                      (int32_t)N, nnz, row_of);
   MP_LAUNCH_CHECK();
   return MP_OK;
@@ -410,7 +448,7 @@ int mp_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val
   int rc = coo_ws_layout(nnz, N, ws, &L);
   if (rc != MP_OK) return rc;
   if (!ws || ws_bytes < L.total) return MP_ERR_WORKSPACE;
-  hipLaunchKernelGGL(transpose_keys_kernel, dim3(flat_grid(nnz)), dim3(kBlock), 0, st, rowptr, col,
+  hipLaunchKernelGGL(transpose_keys_kernel, dim3(flat_grid(ceil_div(nnz, kRowTile) * kBlock)), dim3(kBlock), 0, st, rowptr, col,
                      (int32_t)n_rows, nnz, L.keys_a, L.pay_a);
   MP_LAUNCH_CHECK();
   rocprim::double_buffer<uint64_t> dk(L.keys_a, L.keys_b);

@@ -88,4 +88,5 @@ def ego_batch(base, centres, radius, csr=None):
         g = CSRGraph(outs[TAG_ROWPTR].view(torch.int32)[:n_out + 1], outs[TAG_COL].view(torch.int32)[:nnz], None,
                      outs[TAG_EID].view(torch.int32)[:nnz], n_out, nnz)
         g.symmetric = True
+        g._ego_ids = ((ids.data_ptr(), ids.numel(), ids._version), ids)      # id_branch(ids) takes the ego-batch shortcut
     return ei, orig, ids, ego_of, g

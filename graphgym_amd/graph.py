@@ -184,6 +184,7 @@ class CSRGraph:
         g._plan = self._plan
         g._row_ids = getattr(self, "_row_ids", None)
         g._pattern_of = self if getattr(self, "_pattern_of", None) is None else self._pattern_of
+        g._ego_ids = getattr(self, "_ego_ids", None)
         return g
 
     @property
@@ -420,8 +421,37 @@ class CSRGraph:
         if stamp not in cache:
             if len(cache) > 8:
                 cache.clear()
-            cache[stamp] = (self._id_branch_build(id_index), id_index)
+            ego = getattr(self, "_ego_ids", None)
+            if ego is not None and ego[0] == stamp and self.symmetric:
+                cache[stamp] = (self._id_branch_of_ego_batch(id_index), id_index)
+            else:
+                cache[stamp] = (self._id_branch_build(id_index), id_index)
         return cache[stamp][0]
+
+    def _id_branch_of_ego_batch(self, id_index):
+        """id_branch for the CSR an ego expansion wrote (ego.ego_batch(csr=...)) with the batch's own identity nodes
+        (the centres, new ids 0..B-1): every component holds exactly one identity node, whose id is the smallest of its
+        component — so a row's entry from its centre, if it has one, is the row's FIRST entry, and by symmetry the
+        transposed operator A_id^T is the block of the B centre rows.  A few gathers instead of the general build's
+        passes over all entries (0.67 -> ~0.1 ms at 4096 centres)."""
+        import types
+        _built("id_branch")
+        B, N, dev = id_index.numel(), self.num_nodes, self.device
+        rp = self.rowptr.long()
+        first = rp[:-1].clamp(max=max(self.nnz - 1, 0))
+        src0 = self.col[first].long() if self.nnz else torch.zeros(N, dtype=torch.int64, device=dev)
+        has = (rp[1:] > rp[:-1]) & (src0 < B)
+        rows_m = torch.nonzero(has).view(-1)
+        e_idx = first[rows_m]
+        crp = torch.arange(rows_m.numel() + 1, dtype=torch.int32, device=dev)
+        slot = src0[rows_m].to(torch.int32).contiguous()
+        val = None if self.val is None else self.val[e_idx].contiguous()
+        defer = has.to(torch.uint8)
+        e1 = int(self.rowptr[B].item())
+        t = CSRGraph(self.rowptr[:B + 1], self.col[:e1], None if self.val is None else self.val[:e1], None, B, e1,
+                     self.num_cols)
+        return types.SimpleNamespace(rows=rows_m.to(torch.int32).contiguous(), crp=crp, slot=slot, val=val,
+                                     defer=defer, t=t, n_rows=int(rows_m.numel()))
 
     def _id_branch_build(self, id_index):
         import types

@@ -30,9 +30,10 @@ training loop that means new buffer pairs and new probes in later steps — so t
 allocations only);
 MP_PLACE_ACCEPT the accepted slow-down of the probe against the fastest probe seen (default 0.05: good positions
 measure +0-4 %, conflicting ones +6-12 %); MP_PLACE_BUDGET_MS the probe time a process may spend per device in all
-(default 250 ms — bench.py's one long-lived output takes ~40: a training loop on fresh batches meets new buffers every
-step and would otherwise probe — and synchronise — in every one of them; measured on the ID-GIN ego-batch step: 21 probes
-and +40 ms per step);
+(default 250 ms — bench.py's one long-lived output takes ~40) and MP_PLACE_BUDGET_SEARCHES the allocations that may
+probe anything new in all (default 24): a training loop on fresh batches meets new buffers every step and would otherwise
+probe — and synchronise — in every one of them for ever (measured on the ID-GIN ego-batch step: 13 probes and +30 ms per
+step); past the budget outputs are torch's blocks as they come;
 MP_PLACE_HOLD_FRAC the share of free memory rejected candidates may hold while a search runs (default 0.25).
 """
 import collections
@@ -53,6 +54,7 @@ EXPLORE_TRIES = int(os.environ.get("MP_PLACE_EXPLORE", "8"))   # candidates for 
 EXPLORE_SETS = 2
 ACCEPT = float(os.environ.get("MP_PLACE_ACCEPT", "0.05"))
 BUDGET_MS = float(os.environ.get("MP_PLACE_BUDGET_MS", "250"))   # probe launches a process may spend per device, in all
+BUDGET_SEARCHES = int(os.environ.get("MP_PLACE_BUDGET_SEARCHES", "24"))   # allocations that may probe anything new, in all
 HOLD_FRAC = float(os.environ.get("MP_PLACE_HOLD_FRAC", "0.25"))   # rejected candidates held at once: at most this share of free memory
 MEMO_ENTRIES = 4096
 
@@ -136,7 +138,7 @@ def pair_cost_ms(reads, t, st=None):
         if acc is not None:
             memo.move_to_end(key)
             st["stats"]["memo_hits"] += 1
-        elif st["stats"]["probe_ms_total"] >= BUDGET_MS:
+        elif st["stats"]["probe_ms_total"] >= BUDGET_MS or st["stats"].get("searches", 0) > BUDGET_SEARCHES:
             # a loop whose buffers move every step (a fresh batch per step: new sizes, new addresses) would probe —
             # and synchronise — in every step for ever: a process checks placements until its budget of probes is
             # spent (MP_PLACE_BUDGET_MS of probe launches in all), then takes torch's blocks as they come
@@ -155,6 +157,9 @@ def pair_cost_ms(reads, t, st=None):
         total += nb * acc
         wsum += nb
     ms = total / wsum
+    if cnt and not st.get("_in_search"):
+        st["stats"]["searches"] = st["stats"].get("searches", 0) + 1     # an allocation that met a new pair
+        st["_in_search"] = True
     st["stats"]["probed_pairs"] += cnt
     st["stats"]["probe_ms_total"] += 4.0 * ms * cnt          # two trials, each one untimed + one timed launch (the
     #                                                          budget check above reads this running total)
@@ -182,6 +187,7 @@ def empty_or_torch(shape, device, reads=(), dtype=torch.float32, tries=None, acc
     accept = ACCEPT if accept is None else float(accept)
     st = _dev_state(t.device)
     st["stats"]["allocations"] += 1
+    st["_in_search"] = False
     with _lock, torch.cuda.device(t.device):
         # a segment torch returned to the driver since the last look (empty_cache, an out-of-memory retry) may come back
         # at the same virtual address on different physical memory: remembered probe results would be stale

@@ -127,6 +127,13 @@ def test_csr_written_by_the_expansion_equals_the_csr_built_from_its_edge_list(de
     assert torch.equal(gn.val, wn.val) and gn.symmetric
     x = torch.rand(n2, 64, device=dev)
     assert torch.equal(ops.spmm(gn, x, "sum"), ops.spmm(wn, x, "sum"))
+    # the identity-branch operators through the ego-batch shortcut equal the general build's, field for field
+    fast, slow = gn.id_branch(ids), gn._id_branch_build(ids)
+    for f in ("rows", "crp", "slot", "val", "defer"):
+        assert torch.equal(getattr(fast, f), getattr(slow, f)), f
+    assert fast.n_rows == slow.n_rows and fast.t.nnz == slow.t.nnz and fast.t.num_nodes == slow.t.num_nodes
+    assert torch.equal(fast.t.rowptr, slow.t.rowptr) and torch.equal(fast.t.col, slow.t.col)
+    assert torch.equal(fast.t.val, slow.t.val)
     # its transpose is itself: the same numbers as the sorted transpose of the reference build
     assert gn.transpose() is gn
     assert torch.allclose(ops.spmm(gn.transpose(), x, "sum"), ops.spmm(wn.transpose(), x, "sum"), rtol=1e-6, atol=1e-6)

@@ -472,8 +472,16 @@ def test_attention_pieces(dev):
         return sar.detach(), air.grad, ajr.grad
     r64, r32 = both(ref_add)
     close(sa, (r64[0], r32[0]), what="additive scores")
-    close(aig.grad[:, None], (r64[1][:, None], r32[1][:, None]), what="d a_dst")      # one number per node: per entry
-    close(ajg.grad[:, None], (r64[2][:, None], r32[2][:, None]), what="d a_src")
+    # one number per node, the sum of that node's signed per-entry terms ds_e * lrelu'(z_e): a width-1 result that
+    # cancels by construction, held against its sum of ABSOLUTE terms (rule (d) of tests/_tol.py) — the same closure
+    # with |ds| (lrelu' > 0)
+    def mag_add(c):
+        air, ajr = c(ai).clone().requires_grad_(True), c(aj).clone().requires_grad_(True)
+        torch.nn.functional.leaky_relu(air[rows] + ajr[cols], 0.2).view(-1, 1).backward(c(ds).abs())
+        return air.grad, ajr.grad
+    m64 = both(mag_add)[0]
+    close(aig.grad[:, None], (r64[1][:, None], r32[1][:, None]), what="d a_dst", mag=m64[0][:, None])
+    close(ajg.grad[:, None], (r64[2][:, None], r32[2][:, None]), what="d a_src", mag=m64[1][:, None])
 
 
 # --------------------------------------------------------------------------- full-size properties
