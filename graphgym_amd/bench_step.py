@@ -103,6 +103,7 @@ def run(args, rank, world, dev):
     b0 = pipe.get()
     torch.cuda.synchronize()
     t_build0 = time.perf_counter() - t0
+    pipe.close()                               # (the replayed batch lives on: its step's outputs may be placed)
     for _ in range(warm):
         step_on(b0)
     D.barrier()
@@ -204,6 +205,7 @@ def run(args, rank, world, dev):
             tick()
         torch.cuda.synchronize()
         t_build = D.all_reduce_max((time.perf_counter() - t0) / nb, dev)
+    p.close()
 
     total_nnz = D.all_reduce_sum(nnz_replay, dev)
     total_nodes = D.all_reduce_sum(nodes_replay, dev)

@@ -241,6 +241,8 @@ constexpr int kEgoChunkMax = 512;
 constexpr int kEgoList = 4096;             // LDS words for the ego's sorted member list (or, for a larger ego, a sample of it)
 constexpr int kEgoTable = 8192;            // slots of the LDS hash table (load <= 0.5)
 constexpr int kEgoBlock = 512;
+constexpr int kEgoRec = 4;                 // hits of a row pass 0 records (16-bit positions): pass 1 of such a row is a copy
+constexpr int kEgoHeavyBit = 1 << 30;      // bit 30 of a row's count: more hits than the record holds
 
 struct ChunkCount {   // chunks of ego c (0 for c == B: the scan's total lands there)
   const int64_t* seg;
@@ -272,7 +274,8 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
     const uint32_t* __restrict__ mu, const int64_t* __restrict__ seg, const int64_t* __restrict__ chunk_off,
     const int32_t* __restrict__ wg_ego, int32_t* __restrict__ cnt, const int64_t* __restrict__ eoff,
     int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst, int64_t* __restrict__ orig,
-    int32_t* __restrict__ ego_of, int32_t* __restrict__ csr_col, int32_t* __restrict__ csr_eid) {
+    int32_t* __restrict__ ego_of, int32_t* __restrict__ csr_col, int32_t* __restrict__ csr_eid,
+    uint16_t* __restrict__ rec, int32_t* __restrict__ qc, int32_t* __restrict__ wg_heavy) {
   // membership of the ego in LDS: an open-addressing table original id -> position (tab[h] = position + 1, 0 = empty;
   // keys are compared through list[]) for egos of at most kEgoList members — a miss is one LDS read, a hit two on
   // average; a larger ego keeps every stride-th member in list[] and finishes its searches in global memory
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
   constexpr int kWaves = kEgoBlock / kWave;
   const int64_t wg = blockIdx.x;
   if (wg >= chunk_off[B]) return;             // (the grid is an upper bound: M / chunk + B)
+  if (PASS && wg_heavy[wg] == 0) return;      // pass 1 here is for the members pass 0 could not record (see kEgoRec)
   for (int i = tid; i < kEgoTable; i += kEgoBlock) tab[i] = 0u;
   __syncthreads();
   const int64_t c = wg_ego[wg];               // (ego_wg_kernel: the ego whose chunk range holds wg)
@@ -341,6 +345,11 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
     }
     return (a < S && mu_c[a] == u) ? a : -1;
   };
+  if (!PASS && wg == chunk_off[c] && tid == 0) qc[c] = find((uint32_t)centre);   // the centre's position in its ego
+  __shared__ int heavy_s;
+  if (!PASS && tid == 0) heavy_s = 0;
+  if (!PASS) __syncthreads();
+  const bool can_rec = S <= 65535;            // positions fit the 16-bit records
   // neighbour ids are requested one 64-entry batch ahead: the next batch of this member's row, or the first batch of the
   // wave's next member
   auto fetch = [&](int i, int j0) -> uint32_t {
@@ -358,8 +367,13 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
     int64_t base = 0;
     int has_c = 0;
     if (PASS) {
+      const int cw = cnt[vid];
+      if (!(cw & kEgoHeavyBit)) {             // recorded in pass 0: ego_emit_light_kernel writes it
+        u_ahead = fetch(i + kWaves, i + kWaves < nm ? rs_l[i + kWaves] : 0);
+        continue;
+      }
       base = eoff[vid];
-      has_c = (cnt[vid] >> 31) & 1;
+      has_c = (cw >> 31) & 1;
       if (lane == 0) {
         orig[vid] = (int64_t)v;
         if (ego_of) ego_of[vid] = (int32_t)c;
@@ -376,6 +390,11 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
       const bool hit = q >= 0 && !is_c;
       const unsigned long long m = __ballot(hit);
       const unsigned long long mb = __ballot(hit && u < v);
+      if (!PASS && can_rec && q >= 0) {       // the row's first kEgoRec hits (the centre among them), in walk order
+        const unsigned long long ma = __ballot(q >= 0);
+        const int k = total + (met_c ? 1 : 0) + (int)__popcll(ma & ((1ull << lane) - 1ull));
+        if (k < kEgoRec) rec[p * kEgoRec + k] = (uint16_t)q;
+      }
       met_c = met_c || __ballot(is_c) != 0ull;
       if (PASS && (hit || is_c)) {
         // slot in the row: the centre first, then the other sources by new id (= by original id), the row's own self
@@ -394,8 +413,69 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
       total += (int)__popcll(m);
       below += (int)__popcll(mb);
     }
-    if (!PASS && lane == 0) cnt[vid] = (total + (met_c ? 1 : 0) + (LOOPS ? 1 : 0)) | (met_c ? (int)0x80000000 : 0);
+    if (!PASS && lane == 0) {
+      const bool heavy = !can_rec || total + (met_c ? 1 : 0) > kEgoRec;
+      cnt[vid] = (total + (met_c ? 1 : 0) + (LOOPS ? 1 : 0)) | (met_c ? (int)0x80000000 : 0) | (heavy ? kEgoHeavyBit : 0);
+      if (heavy) heavy_s = 1;
+    }
     if (PASS && LOOPS && csr_col && lane == 0) {
+      const int slot = vid < B ? 0 : has_c + below;
+      csr_col[base + slot] = (int32_t)vid;
+      csr_eid[base + slot] = -1 - (int32_t)vid;
+    }
+  }
+  if (!PASS) {
+    __syncthreads();
+    if (tid == 0) wg_heavy[wg] = heavy_s;
+  }
+}
+
+// Pass 1 for the recorded members — nearly all of them: a member of the outermost level has its parent and seldom more
+// than a neighbour or two inside the ego.  One thread per member writes its row from the record: positions inside the ego
+// give the new ids (the centre's position qc[c] tells which one is the centre and which ids lie behind it), the member's
+// own position where its self entry goes.  No walk over the neighbour lists, no membership test.
+template <bool LOOPS>
+__global__ __launch_bounds__(kBlock) void ego_emit_light_kernel(
+    const uint64_t* __restrict__ members, int64_t M, int64_t B, const int64_t* __restrict__ seg,
+    const int32_t* __restrict__ qc, const int32_t* __restrict__ cnt, const int64_t* __restrict__ eoff,
+    const uint16_t* __restrict__ rec, int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst,
+    int64_t* __restrict__ orig, int32_t* __restrict__ ego_of, int32_t* __restrict__ csr_col,
+    int32_t* __restrict__ csr_eid) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < M; p += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = members[p];
+    const int64_t c = key_c(key);
+    const uint32_t v = key_u(key);
+    const int64_t s0 = seg[c];
+    const int qv = (int)(p - s0), qcc = qc[c];
+    auto id_of = [&](int q) -> int64_t { return q == qcc ? c : B + s0 + q - c - (q > qcc ? 1 : 0); };
+    const int64_t vid = id_of(qv);
+    const int cw = cnt[vid];
+    if (cw & kEgoHeavyBit) continue;          // the chunk kernel's pass 1 writes it
+    orig[vid] = (int64_t)v;
+    if (ego_of) ego_of[vid] = (int32_t)c;
+    const int has_c = (cw >> 31) & 1;
+    const int H = (cw & 0x3fffffff) - (LOOPS ? 1 : 0);      // recorded hits, the centre among them
+    const int64_t base = eoff[vid];
+    int rank = 0, below = 0;
+    for (int k = 0; k < H; ++k) {
+      const int q = rec[p * kEgoRec + k];
+      const bool is_c = q == qcc;
+      const bool after_self = LOOPS && !is_c && (vid < B || q > qv);
+      const int slot = is_c ? 0 : has_c + rank + (after_self ? 1 : 0);
+      const int64_t hit_id = id_of(q);
+      const int64_t o = base + slot - (LOOPS ? vid + (after_self ? 1 : 0) : 0);
+      out_dst[o] = vid;
+      out_src[o] = hit_id;
+      if (csr_col) {
+        csr_col[base + slot] = (int32_t)hit_id;
+        csr_eid[base + slot] = (int32_t)o;
+      }
+      if (!is_c) {
+        ++rank;
+        if (q < qv) ++below;
+      }
+    }
+    if (LOOPS && csr_col) {
       const int slot = vid < B ? 0 : has_c + below;
       csr_col[base + slot] = (int32_t)vid;
       csr_eid[base + slot] = -1 - (int32_t)vid;
@@ -403,10 +483,10 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
   }
 }
 
-struct CountAsI64 {   // (bit 31 of a count is the "meets its centre" flag of the chunk kernel)
+struct CountAsI64 {   // (bits 31 / 30 of a count: "meets its centre" / "not recorded" flags of the chunk kernel)
   const int32_t* cnt;
   int64_t M;
-  __device__ int64_t operator()(int64_t i) const { return i < M ? (int64_t)(cnt[i] & 0x7fffffff) : 0; }
+  __device__ int64_t operator()(int64_t i) const { return i < M ? (int64_t)(cnt[i] & 0x3fffffff) : 0; }
 };
 
 // wg_ego[w] = the ego whose chunk range holds workgroup w (last c with chunk_off[c] <= w): one thread per workgroup, once,
@@ -600,9 +680,17 @@ int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N, const in
     hipLaunchKernelGGL(ego_wg_kernel, dim3((unsigned)ceil_div(n_wg, kBlock)), dim3(kBlock), 0, st, chunk_off, B, n_wg, wg_ego);
     EGO_LAUNCH_CHECK();
   }
+  uint16_t* rec = nullptr;
+  int32_t *qc = nullptr, *wg_heavy = nullptr;
+  if (!whole) {
+    rec = reinterpret_cast<uint16_t*>(mem.take((size_t)M * kEgoRec * 2));
+    qc = reinterpret_cast<int32_t*>(mem.take((size_t)B * 4));
+    wg_heavy = reinterpret_cast<int32_t*>(mem.take((size_t)n_wg * 4));
+    if (!rec || !qc || !wg_heavy) { mem.give_all(); return MP_ERR_WORKSPACE; }
+  }
 #define EGO_CHUNK_LAUNCH(PASS, LOOPS, ...) \
   hipLaunchKernelGGL((ego_edges_chunk_kernel<PASS, kChunk, LOOPS>), cgrid, dim3(kEgoBlock), 0, st, rowptr, col, centres, B, \
-                     mu, seg, chunk_off, wg_ego, __VA_ARGS__)
+                     mu, seg, chunk_off, wg_ego, __VA_ARGS__, rec, qc, wg_heavy)
   if (whole)
     hipLaunchKernelGGL((ego_edges_kernel<0, true>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
                        seg, (const uint32_t*)nullptr, 0u, cnt, eoff, nullptr, nullptr, nullptr, nullptr);
@@ -646,10 +734,15 @@ int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N, const in
   if (whole)
     hipLaunchKernelGGL((ego_edges_kernel<1, true>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
                        seg, (const uint32_t*)nullptr, 0u, nullptr, eoff, o_src, o_dst, o_orig, o_ego);
-  else if (loops)
+  else if (loops) {
+    hipLaunchKernelGGL((ego_emit_light_kernel<true>), dim3(flat_grid(M)), dim3(kBlock), 0, st, members, M, B, seg, qc, cnt,
+                       eoff, rec, o_src, o_dst, o_orig, o_ego, o_col, o_eid);
     EGO_CHUNK_LAUNCH(1, true, cnt, eoff, o_src, o_dst, o_orig, o_ego, o_col, o_eid);
-  else
+  } else {
+    hipLaunchKernelGGL((ego_emit_light_kernel<false>), dim3(flat_grid(M)), dim3(kBlock), 0, st, members, M, B, seg, qc, cnt,
+                       eoff, rec, o_src, o_dst, o_orig, o_ego, o_col, o_eid);
     EGO_CHUNK_LAUNCH(1, false, cnt, eoff, o_src, o_dst, o_orig, o_ego, o_col, o_eid);
+  }
   EGO_LAUNCH_CHECK();
 #undef EGO_CHUNK_LAUNCH
   out->n_nodes = M;

@@ -58,6 +58,11 @@ class EgoBatchPipeline:
         self._pending = None
         self._first = True
         self._pool = None
+        # a batch's buffers live for one step: no (read, output) pair of the aggregation launches is ever seen twice, so
+        # placement checks (graphgym_amd/placement.py) could only cost — they are off while a pipeline is open
+        from . import placement
+        placement.pause()
+        self._paused = True
         if threaded:
             import concurrent.futures
             self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="mp-batch")
@@ -133,6 +138,10 @@ class EgoBatchPipeline:
     def close(self):
         torch.cuda.current_stream(self.device).synchronize()
         self._held.clear()
+        if self._paused:
+            from . import placement
+            placement.resume()
+            self._paused = False
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None

@@ -31,7 +31,7 @@ allocations only);
 MP_PLACE_ACCEPT the accepted slow-down of the probe against the fastest probe seen (default 0.05: good positions
 measure +0-4 %, conflicting ones +6-12 %); MP_PLACE_BUDGET_MS the probe time a process may spend per device in all
 (default 250 ms — bench.py's one long-lived output takes ~40) and MP_PLACE_BUDGET_SEARCHES the allocations that may
-probe anything new in all (default 24): a training loop on fresh batches meets new buffers every step and would otherwise
+probe anything new in all (default 12): a training loop on fresh batches meets new buffers every step and would otherwise
 probe — and synchronise — in every one of them for ever (measured on the ID-GIN ego-batch step: 13 probes and +30 ms per
 step); past the budget outputs are torch's blocks as they come;
 MP_PLACE_HOLD_FRAC the share of free memory rejected candidates may hold while a search runs (default 0.25).
@@ -54,7 +54,7 @@ EXPLORE_TRIES = int(os.environ.get("MP_PLACE_EXPLORE", "8"))   # candidates for 
 EXPLORE_SETS = 2
 ACCEPT = float(os.environ.get("MP_PLACE_ACCEPT", "0.05"))
 BUDGET_MS = float(os.environ.get("MP_PLACE_BUDGET_MS", "250"))   # probe launches a process may spend per device, in all
-BUDGET_SEARCHES = int(os.environ.get("MP_PLACE_BUDGET_SEARCHES", "24"))   # allocations that may probe anything new, in all
+BUDGET_SEARCHES = int(os.environ.get("MP_PLACE_BUDGET_SEARCHES", "12"))   # allocations that may probe anything new, in all
 HOLD_FRAC = float(os.environ.get("MP_PLACE_HOLD_FRAC", "0.25"))   # rejected candidates held at once: at most this share of free memory
 MEMO_ENTRIES = 4096
 
@@ -90,8 +90,22 @@ def _segments_freed(device):
         return 0
 
 
+_paused = [0]
+
+
+def pause():
+    """stop checking placements (outputs are plain torch allocations) until resume(): for loops whose large buffers live for
+    ONE step — a fresh batch every step (graphgym_amd/pipeline.py) — where no (read, output) pair is ever seen twice, a
+    check can only cost (a search holds candidates: new 1 GiB blocks from the driver, ~20 ms each)"""
+    _paused[0] += 1
+
+
+def resume():
+    _paused[0] = max(0, _paused[0] - 1)
+
+
 def enabled():
-    return os.environ.get("MP_PLACEMENT", "auto") != "off"
+    return os.environ.get("MP_PLACEMENT", "auto") != "off" and _paused[0] == 0
 
 
 def _dev_state(device):
