@@ -241,6 +241,7 @@ constexpr int kEgoChunkMax = 512;
 constexpr int kEgoList = 4096;             // LDS words for the ego's sorted member list (or, for a larger ego, a sample of it)
 constexpr int kEgoTable = 8192;            // slots of the LDS hash table (load <= 0.5)
 constexpr int kEgoBlock = 512;
+constexpr uint32_t kEgoEmpty = 0xffffffffu; // (node ids are < 2^31)
 constexpr int kEgoRec = 4;                 // hits of a row pass 0 records (16-bit positions): pass 1 of such a row is a copy
 constexpr int kEgoHeavyBit = 1 << 30;      // bit 30 of a row's count: more hits than the record holds
 
@@ -253,11 +254,9 @@ struct ChunkCount {   // chunks of ego c (0 for c == B: the scan's total lands t
   }
 };
 
-__device__ __forceinline__ uint32_t ego_hash1(uint32_t u) {
-  uint32_t h = u * 0x9E3779B1u;
-  h ^= h >> 15;
-  h *= 0x2C1B3C6Du;
-  return (h ^ (h >> 13)) & (uint32_t)(kEgoTable - 1);
+__device__ __forceinline__ uint32_t ego_hash1(uint32_t u) {   // multiplicative hashing: the top 13 bits of u * golden ratio
+  static_assert(kEgoTable == 1 << 13, "ego_hash1 returns 13 bits");
+  return (u * 0x9E3779B1u) >> 19;
 }
 
 // Output order: rows by NEW id (centres 0..B-1 first, then every ego's other members), inside a row by new source id —
@@ -279,8 +278,10 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
   // membership of the ego in LDS: an open-addressing table original id -> position (tab[h] = position + 1, 0 = empty;
   // keys are compared through list[]) for egos of at most kEgoList members — a miss is one LDS read, a hit two on
   // average; a larger ego keeps every stride-th member in list[] and finishes its searches in global memory
-  __shared__ uint32_t tab[kEgoTable];
-  __shared__ uint32_t list[kEgoList];
+  __shared__ uint32_t tab[kEgoTable];         // hashed egos: the member's original id (kEgoEmpty = free slot)
+  __shared__ uint32_t list[kEgoList];         // hashed egos: uint16 positions of the slots (2 per word); else the sample
+  uint16_t* const pos_t = reinterpret_cast<uint16_t*>(list);
+  static_assert(kEgoTable * 2 <= kEgoList * 4, "the positions of the table's slots fit the list's words");
   __shared__ int32_t rs_l[kEgoChunk], re_l[kEgoChunk];
   __shared__ uint32_t v_l[kEgoChunk];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
   const int64_t wg = blockIdx.x;
   if (wg >= chunk_off[B]) return;             // (the grid is an upper bound: M / chunk + B)
   if (PASS && wg_heavy[wg] == 0) return;      // pass 1 here is for the members pass 0 could not record (see kEgoRec)
-  for (int i = tid; i < kEgoTable; i += kEgoBlock) tab[i] = 0u;
+  for (int i = tid; i < kEgoTable; i += kEgoBlock) tab[i] = kEgoEmpty;
   __syncthreads();
   const int64_t c = wg_ego[wg];               // (ego_wg_kernel: the ego whose chunk range holds wg)
   const int64_t s0 = seg[c], s1 = seg[c + 1];
@@ -303,18 +304,25 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
   if (hashed) {
     for (int i = tid; i < S; i += kEgoBlock) {
       const uint32_t u = mu_c[i];
-      list[i] = u;
       uint32_t h = ego_hash1(u);
-      while (atomicCAS(&tab[h], 0u, (uint32_t)i + 1u) != 0u) h = (h + 1u) & (uint32_t)(kEgoTable - 1);
+      while (atomicCAS(&tab[h], kEgoEmpty, u) != kEgoEmpty) h = (h + 1u) & (uint32_t)(kEgoTable - 1);
+      pos_t[h] = (uint16_t)i;
     }
   } else {
     for (int i = tid; i < n_s; i += kEgoBlock) list[i] = mu_c[(int64_t)i * stride];
   }
+  __shared__ int32_t cw_l[PASS ? kEgoChunk : 1];     // pass 1: the members' counts (flags) and row offsets, fetched by the
+  __shared__ int64_t base_l[PASS ? kEgoChunk : 1];   // whole workgroup at once instead of one dependent load per member
   for (int i = tid; i < nm; i += kEgoBlock) {
     const uint32_t v = mu[m0 + i];
     v_l[i] = v;
     rs_l[i] = rowptr[v];
     re_l[i] = rowptr[v + 1];
+    if (PASS) {
+      const int64_t vid = (int64_t)v == centre ? c : B + (m0 + i) - c - ((int64_t)v > centre ? 1 : 0);
+      cw_l[i] = cnt[vid];
+      base_l[i] = eoff[vid];
+    }
   }
   __syncthreads();
   auto new_id = [&](int q, uint32_t u) -> int64_t {          // q: position inside the ego
@@ -323,12 +331,12 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
   };
   // position of u among the ego's members, or -1
   auto find = [&](uint32_t u) -> int {
-    if (hashed) {
+    if (hashed) {                                             // one LDS read decides a miss; a hit reads its position
       uint32_t h = ego_hash1(u);
       for (;;) {
         const uint32_t t = tab[h];
-        if (t == 0u) return -1;
-        if (list[t - 1u] == u) return (int)(t - 1u);
+        if (t == kEgoEmpty) return -1;
+        if (t == u) return (int)pos_t[h];
         h = (h + 1u) & (uint32_t)(kEgoTable - 1);
       }
     }
@@ -357,22 +365,29 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
     const int j = j0 + lane;
     return j < re_l[i] ? ((uint32_t)col[j] & 0x7fffffffu) : 0u;
   };
-  int i = wave;
-  uint32_t u_ahead = i < nm ? fetch(i, rs_l[i]) : 0u;
-  for (; i < nm; i += kWaves) {
-    const int rs = rs_l[i], re = re_l[i];
+  // One member: its row's neighbour ids in batches of 64 (the next batch of a long row is requested one ahead).
+  // What the wave shares — row bounds, the member's ids, counters, offsets — is made SCALAR (readfirstlane: the scalar unit
+  // issues beside the vector one), masks are counted on the scalar unit, the first probe of the table is inline and
+  // everything behind it sits under wave-uniform branches that a batch without hits or collisions skips.  (Ablations of
+  // this pass at 4 096 centres of BA(2 * 10^6, 5), round 4: whole pass 1.35 ms; without the member loop 0.10; without the
+  // membership test 0.59; without the neighbour-id loads 1.05; without both 0.38.  Prefetch depth 1 -> 4, an LDS stage of
+  // the chunk's neighbour ids, a keyed table, a deal of the members by work: 1.31-1.35 each; this scalar form: 1.19.)
+  const uint32_t centre32 = (uint32_t)centre;
+  const int64_t idbase = B + s0 - c;          // new id of the member at position q (not the centre): idbase + q - [q > qc]
+  auto process = [&](int i, uint32_t u_first) {
+    const int rs = __builtin_amdgcn_readfirstlane(rs_l[i]), re = __builtin_amdgcn_readfirstlane(re_l[i]);
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v_l[i]);
+    const int qv = (int)(m0 - s0) + i;
     const int64_t p = m0 + i;
-    const uint32_t v = v_l[i];
-    const int64_t vid = new_id((int)(p - s0), v);
+    const int64_t vid = v == centre32 ? c : idbase + qv - (v > centre32 ? 1 : 0);
     int64_t base = 0;
     int has_c = 0;
     if (PASS) {
-      const int cw = cnt[vid];
-      if (!(cw & kEgoHeavyBit)) {             // recorded in pass 0: ego_emit_light_kernel writes it
-        u_ahead = fetch(i + kWaves, i + kWaves < nm ? rs_l[i + kWaves] : 0);
-        continue;
-      }
-      base = eoff[vid];
+      const int cw = __builtin_amdgcn_readfirstlane(cw_l[i]);
+      if (!(cw & kEgoHeavyBit)) return;       // recorded in pass 0: ego_emit_light_kernel writes it
+      const int64_t bl = base_l[i];
+      base = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bl >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)bl));
       has_c = (cw >> 31) & 1;
       if (lane == 0) {
         orig[vid] = (int64_t)v;
@@ -381,18 +396,39 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
     }
     int total = 0, below = 0;                 // non-centre hits so far; those with a smaller original id than v
     bool met_c = false;
-    if (rs >= re) u_ahead = fetch(i + kWaves, i + kWaves < nm ? rs_l[i + kWaves] : 0);     // (a member without entries)
+    uint32_t u_ahead = u_first;
     for (int j0 = rs; j0 < re; j0 += kWave) {
       const uint32_t u = u_ahead;
-      u_ahead = j0 + kWave < re ? fetch(i, j0 + kWave) : fetch(i + kWaves, i + kWaves < nm ? rs_l[i + kWaves] : 0);
-      const int q = j0 + lane < re ? find(u) : -1;
-      const bool is_c = q >= 0 && (int64_t)u == centre;
+      if (j0 + kWave < re) u_ahead = fetch(i, j0 + kWave);
+      const bool valid = j0 + lane < re;
+      int q = -1;
+      if (hashed) {
+        uint32_t h = ego_hash1(u);
+        const uint32_t t = valid ? tab[h] : kEgoEmpty;
+        const bool eq = t == u;
+        if (__ballot(t != kEgoEmpty && !eq) != 0ull) {       // some lane met another key: that lane walks on
+          uint32_t tt = t;
+          while (tt != kEgoEmpty && tt != u) {
+            h = (h + 1u) & (uint32_t)(kEgoTable - 1);
+            tt = tab[h];
+          }
+          if (tt == u) q = (int)pos_t[h];
+        } else if (__ballot(eq) != 0ull) {
+          if (eq) q = (int)pos_t[h];
+        }
+      } else if (valid) {
+        q = find(u);
+      }
+      const unsigned long long ma = __ballot(q >= 0);
+      if (ma == 0ull) continue;               // no neighbour of this batch is a member
+      const bool is_c = q >= 0 && u == centre32;
       const bool hit = q >= 0 && !is_c;
       const unsigned long long m = __ballot(hit);
       const unsigned long long mb = __ballot(hit && u < v);
+      const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       if (!PASS && can_rec && q >= 0) {       // the row's first kEgoRec hits (the centre among them), in walk order
-        const unsigned long long ma = __ballot(q >= 0);
-        const int k = total + (met_c ? 1 : 0) + (int)__popcll(ma & ((1ull << lane) - 1ull));
+        const int k = total + (met_c ? 1 : 0) +
+                      (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
         if (k < kEgoRec) rec[p * kEgoRec + k] = (uint16_t)q;
       }
       met_c = met_c || __ballot(is_c) != 0ull;
@@ -400,8 +436,8 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
         // slot in the row: the centre first, then the other sources by new id (= by original id), the row's own self
         // entry (LOOPS) between the smaller and the larger ones; a centre's row holds only larger ones
         const bool after_self = LOOPS && !is_c && (vid < B || u > v);   // (the centre's id is below every row's)
-        const int slot = is_c ? 0 : has_c + total + (int)__popcll(m & ((1ull << lane) - 1ull)) + (after_self ? 1 : 0);
-        const int64_t hit_id = is_c ? c : new_id(q, u);
+        const int slot = is_c ? 0 : has_c + total + before + (after_self ? 1 : 0);
+        const int64_t hit_id = is_c ? c : idbase + q - (u > centre32 ? 1 : 0);
         const int64_t o = base + slot - (LOOPS ? vid + (after_self ? 1 : 0) : 0);      // position without the self entries
         out_dst[o] = vid;                     // row v holds v's in-edges
         out_src[o] = hit_id;
@@ -423,6 +459,37 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
       csr_col[base + slot] = (int32_t)vid;
       csr_eid[base + slot] = -1 - (int32_t)vid;
     }
+  };
+  // The chunk's members are dealt to the waves by WORK, not by count: rows of a scale-free graph differ by three orders of
+  // magnitude in length, and a wave that drew two hub rows in a deal by index kept its workgroup (and its LDS) alive
+  // long after the other seven had finished.  off_s = exclusive prefix of the rows' batch counts (one wave scans the
+  // chunk, two members per lane); wave w takes the members whose prefix starts in its eighth of the total.
+  __shared__ int32_t off_s[kEgoChunk + 1];
+  static_assert(kEgoChunk == 2 * kWave, "the batch counts are scanned by one wave, two members per lane");
+  if (wave == 0) {
+    const int i0 = 2 * lane, i1 = 2 * lane + 1;
+    const int a = i0 < nm ? (re_l[i0] - rs_l[i0] + kWave - 1) / kWave + 1 : 0;      // (+ 1: a row costs a visit even if empty)
+    const int bb = i1 < nm ? (re_l[i1] - rs_l[i1] + kWave - 1) / kWave + 1 : 0;
+    int incl = a + bb;
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int t = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += t;
+    }
+    const int excl = incl - (a + bb);
+    off_s[i0] = excl;
+    off_s[i1] = excl + a;
+    if (lane == kWave - 1) off_s[kEgoChunk] = incl;
+  }
+  __syncthreads();
+  {
+    const int T = off_s[kEgoChunk];
+    const int w_lo = (int)((int64_t)T * wave / kWaves), w_hi = (int)((int64_t)T * (wave + 1) / kWaves);
+    int lo = 0, hi = nm;                      // first member whose prefix is >= w_lo
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (off_s[mid] < w_lo) lo = mid + 1; else hi = mid;
+    }
+    for (int i = lo; i < nm && off_s[i] < w_hi; ++i) process(i, fetch(i, rs_l[i]));
   }
   if (!PASS) {
     __syncthreads();

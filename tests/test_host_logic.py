@@ -292,3 +292,29 @@ def test_inactive_grad_bucket_allows_gradient_accumulation():
     ref.load_state_dict(lin.state_dict())
     (ref(x).sum() * 2).backward()
     assert torch.allclose(lin.weight.grad, ref.weight.grad) and torch.allclose(lin.bias.grad, ref.bias.grad)
+
+
+def test_effective_cpus_respects_the_cgroup_quota_and_fits_torch():
+    """hostcpu: the usable CPU count is bounded by affinity and cgroup quota; fit_torch_threads never raises the pool"""
+    from graphgym_amd import hostcpu
+    n = hostcpu.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            assert n <= max(1, int(int(q) / int(p)))
+    except OSError:
+        pass
+    before = torch.get_num_threads()
+    assert hostcpu.fit_torch_threads() <= max(before, n)
+
+
+def test_quiet_gc_disables_automatic_collection_and_restores_it():
+    import gc
+    from graphgym_amd.pipeline import quiet_gc
+    assert gc.isenabled()
+    with quiet_gc() as tick:
+        assert not gc.isenabled()
+        for _ in range(20):
+            tick()
+    assert gc.isenabled()
