@@ -275,9 +275,9 @@ __global__ __launch_bounds__(kEgoBlock) void ego_edges_chunk_kernel(
     int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst, int64_t* __restrict__ orig,
     int32_t* __restrict__ ego_of, int32_t* __restrict__ csr_col, int32_t* __restrict__ csr_eid,
     uint16_t* __restrict__ rec, int32_t* __restrict__ qc, int32_t* __restrict__ wg_heavy) {
-  // membership of the ego in LDS: an open-addressing table original id -> position (tab[h] = position + 1, 0 = empty;
-  // keys are compared through list[]) for egos of at most kEgoList members — a miss is one LDS read, a hit two on
-  // average; a larger ego keeps every stride-th member in list[] and finishes its searches in global memory
+  // membership of the ego in LDS: an open-addressing table keyed by original id (tab[h] = id, kEgoEmpty = free; the
+  // member's position sits in pos_t[h]) for egos of at most kEgoList members — a miss is one LDS read, a hit two; a
+  // larger ego keeps every stride-th member in list[] and finishes its searches in global memory
   __shared__ uint32_t tab[kEgoTable];         // hashed egos: the member's original id (kEgoEmpty = free slot)
   __shared__ uint32_t list[kEgoList];         // hashed egos: uint16 positions of the slots (2 per word); else the sample
   uint16_t* const pos_t = reinterpret_cast<uint16_t*>(list);
