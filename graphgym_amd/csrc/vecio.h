@@ -22,6 +22,20 @@ template <> __device__ __forceinline__ void load_vec<2>(const float* p, float (&
 }
 template <> __device__ __forceinline__ void load_vec<1>(const float* p, float (&v)[1]) { v[0] = *p; }
 
+// streaming (non-temporal) load of a row that this kernel reads once: it should not push resident data (the transform's
+// weights) out of the L2
+template <int W> __device__ __forceinline__ void load_vec_nt(const float* p, float (&v)[W]) {
+  if constexpr (W == 4) {
+    f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else if constexpr (W == 2) {
+    f32x2 t = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+    v[0] = t[0]; v[1] = t[1];
+  } else {
+    v[0] = __builtin_nontemporal_load(p);
+  }
+}
+
 template <int W> __device__ __forceinline__ void store_vec(float* p, const float (&v)[W]);
 template <> __device__ __forceinline__ void store_vec<4>(float* p, const float (&v)[4]) {
   f32x4 t = {v[0], v[1], v[2], v[3]};
