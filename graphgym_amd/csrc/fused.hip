@@ -27,9 +27,6 @@
 // entries whose source is an identity node.  The main kernel leaves rows that own such an entry un-activated
 // (`defer_act`), and id_fixup_kernel adds A_id Z to exactly those rows and applies the activation.
 #include "common.h"
-#ifndef MP_PC_NT_X
-#define MP_PC_NT_X 0   // study build: non-temporal loads of the gathered rows in the layer kernels (scripts/dbg/fused_ab.py)
-#endif
 #include <map>
 #include <mutex>
 #include <utility>
@@ -895,11 +892,11 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
           auto issue_burst = [&](int cvb, int jb, const float* __restrict__ xl) {
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-#if MP_PC_NT_X
-              if constexpr (!AGG_ONLY) load_vec_nt<W>(xl + (int64_t)bcast_i(cvb, jb + j) * a.ldx, vb[j]);
-              else
-#endif
-              load_vec<W>(xl + (int64_t)bcast_i(cvb, jb + j) * a.ldx, vb[j]);
+              // F = 512 (two K halves): the gathered rows are read once and stream past 1.5 MB of split W that every tile
+              // re-reads from L2 — non-temporal loads keep them from pushing W out (round 4, in-process A/B on the same
+              // buffers: 52.1 -> 51.0 ms; at F = 256, where W is 0.4 MB, no difference: left as plain loads)
+              if constexpr (!AGG_ONLY && KH == 2) load_vec_nt<W>(xl + (int64_t)bcast_i(cvb, jb + j) * a.ldx, vb[j]);
+              else load_vec<W>(xl + (int64_t)bcast_i(cvb, jb + j) * a.ldx, vb[j]);
             }
           };
           auto consume_burst = [&](int ec, int jb, float wvb) {
@@ -958,11 +955,8 @@ void agg_dense_pc_kernel(FusedArgs a, unsigned int* __restrict__ tile_ctr, int32
           const int c1 = cv1 & 0x7fffffff;
 #pragma unroll
           for (int j = 0; j < U; ++j) {
-#if MP_PC_NT_X
-            if constexpr (!AGG_ONLY) load_vec_nt<W>(xl1 + (int64_t)bcast_i(c1, j) * a.ldx, vb[j]);
-            else
-#endif
-            load_vec<W>(xl1 + (int64_t)bcast_i(c1, j) * a.ldx, vb[j]);
+            if constexpr (!AGG_ONLY && KH == 2) load_vec_nt<W>(xl1 + (int64_t)bcast_i(c1, j) * a.ldx, vb[j]);
+            else load_vec<W>(xl1 + (int64_t)bcast_i(c1, j) * a.ldx, vb[j]);
           }
           pre = true;
         }

@@ -50,6 +50,14 @@ def pytest_sessionfinish(session, exitstatus):
                        "rows": rows, "rows_needing_ref32": needed,
                        "straggler_rows": sum(s.get("stragglers", 0) for s in _tol.STATS),
                        "calls_with_stragglers": [s["what"] for s in _tol.STATS if s.get("stragglers")],
+                       # rule (c) and the straggler clause exist under deep=True only (whole-model comparisons)
+                       "deep_calls": sum(1 for s in _tol.STATS if s.get("deep")),
+                       "deep_call_names": sorted({s["what"] for s in _tol.STATS if s.get("deep")}),
+                       "straggler_rows_outside_deep_calls": sum(s.get("stragglers", 0) for s in _tol.STATS
+                                                                if not s.get("deep")),
+                       "rule_c_rows": sum(s.get("rule_c_rows", 0) for s in _tol.STATS),
+                       "rule_c_rows_outside_deep_calls": sum(s.get("rule_c_rows", 0) for s in _tol.STATS
+                                                             if not s.get("deep")),
                        "largest_fractions": worst}, f, indent=1)
     except Exception:
         pass
