@@ -414,6 +414,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--centres", type=int, default=4096, help="step: ego-net centres per GPU in the global batch")
     ap.add_argument("--step-model", choices=["idgcn", "idgin"], default="idgcn")
+    ap.add_argument("--step-nodes", type=int, default=2_000_000, help="step: nodes of the base graph the ego nets are cut from")
     ap.add_argument("--step-steps", type=int, default=20, help="timed steps of the `step` object in --mode both")
     args = ap.parse_args()
     if args.gpus < 1:

@@ -44,7 +44,7 @@ def run(args, rank, world, dev):
     from graphgym_amd.pipeline import EgoBatchPipeline, quiet_gc
 
     kind = getattr(args, "step_model", "idgcn")
-    n0 = min(args.nodes, 2_000_000)
+    n0 = min(args.nodes, getattr(args, "step_nodes", 2_000_000))
     f_in, d = (128, 128) if kind == "idgcn" else (512, 512)
     classes, radius = 7, 2
     ei = graphgen.ba_edge_index(n0, args.m, seed=12345, device=dev)          # the same base graph on every rank
