@@ -123,50 +123,25 @@ __global__ __launch_bounds__(kBlock) void ego_seg_kernel(const uint64_t* __restr
   seg[c] = lo;
 }
 
-__device__ __forceinline__ uint32_t ego_hash(uint32_t c, uint32_t u) {
-  uint32_t h = u * 0x9E3779B1u ^ (c + 0x7F4A7C15u) * 0x85EBCA77u;
-  h ^= h >> 15;
-  h *= 0x2C1B3C6Du;
-  return h ^ (h >> 13);
-}
-
-// the member ids as 32-bit words (the searches read half the bytes) and the hash filter: one bit per member among
-// `fbits` = 2^k >= 16 M
+// the member ids as 32-bit words: what the edge passes read
 __global__ __launch_bounds__(kBlock) void ego_index_kernel(const uint64_t* __restrict__ members, int64_t M,
-                                                           uint32_t* __restrict__ mu, uint32_t* __restrict__ filter,
-                                                           uint32_t fmask) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint64_t k = members[i];
-    const uint32_t u = key_u(k);
-    mu[i] = u;
-    if (filter) {
-      const uint32_t h = ego_hash(key_c(k), u) & fmask;
-      atomicOr(&filter[h >> 5], 1u << (h & 31));
-    }
-  }
+                                                           uint32_t* __restrict__ mu) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x)
+    mu[i] = key_u(members[i]);
 }
 
-// position of (c, u) in the member list, or -1
-__device__ __forceinline__ int64_t ego_find(const uint32_t* __restrict__ mu, int64_t s, int64_t e, uint32_t u) {
-  while (s < e) {
-    const int64_t mid = (s + e) >> 1;
-    const uint32_t v = mu[mid];
-    if (v < u) s = mid + 1; else e = mid;
-  }
-  return s;   // lower bound; the caller compares
-}
-
-// PASS 0: cnt[p] = induced in-edges of member p.  PASS 1: emit them at eoff[p]..., and orig / ego_of of p's new id.
-// One wave per member; WHOLE: every node is a member, position = c N + u.
-template <int PASS, bool WHOLE>
-__global__ __launch_bounds__(kBlock) void ego_edges_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                           const int64_t* __restrict__ centres, int64_t B, int64_t N,
-                                                           const uint64_t* __restrict__ members, int64_t M,
-                                                           const uint32_t* __restrict__ mu, const int64_t* __restrict__ seg,
-                                                           const uint32_t* __restrict__ filter, uint32_t fmask,
-                                                           int32_t* __restrict__ cnt, const int64_t* __restrict__ eoff,
-                                                           int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst,
-                                                           int64_t* __restrict__ orig, int32_t* __restrict__ ego_of) {
+// radius > 4 (every node of the graph is a member of every ego: transform.py:17-18): a wave per member copies the
+// member's row — every neighbour is a member, its position is c N + u.  PASS 0: cnt[p] = the row's length;
+// PASS 1: the entries at eoff[p]..., orig / ego_of of p's new id.  (The edge list is in member order here; the CSR-order
+// emission and the CSR output belong to the chunk kernel below.)
+template <int PASS>
+__global__ __launch_bounds__(kBlock) void ego_edges_whole_kernel(const int32_t* __restrict__ rowptr,
+                                                                 const int32_t* __restrict__ col,
+                                                                 const int64_t* __restrict__ centres, int64_t B, int64_t N,
+                                                                 const uint64_t* __restrict__ members, int64_t M,
+                                                                 int32_t* __restrict__ cnt, const int64_t* __restrict__ eoff,
+                                                                 int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst,
+                                                                 int64_t* __restrict__ orig, int32_t* __restrict__ ego_of) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -174,63 +149,34 @@ __global__ __launch_bounds__(kBlock) void ego_edges_kernel(const int32_t* __rest
     const uint64_t k = members[p];
     const uint32_t c = key_c(k), v = key_u(k);
     const int64_t centre = centres[c];
-    const int64_t s0 = WHOLE ? (int64_t)c * N : seg[c];
-    const int64_t s1 = WHOLE ? s0 + N : seg[c + 1];
+    const int64_t s0 = (int64_t)c * N;
     auto new_id = [&](int64_t q, uint32_t u) -> int64_t {
       if ((int64_t)u == centre) return (int64_t)c;
       return B + q - (int64_t)c - ((int64_t)u > centre ? 1 : 0);
     };
-    int64_t vid = 0, base = 0;
-    if (PASS) {
-      vid = new_id(p, v);
-      base = eoff[p];
-      if (lane == 0) {
-        orig[vid] = (int64_t)v;
-        if (ego_of) ego_of[vid] = (int32_t)c;
-      }
-    }
     const int rs = rowptr[v], re = rowptr[v + 1];
-    int total = 0;
-    for (int j0 = rs; j0 < re; j0 += kWave) {
-      const int j = j0 + lane;
-      bool hit = false;
-      int64_t q = -1;
-      uint32_t u = 0;
-      if (j < re) {
-        u = (uint32_t)col[j] & 0x7fffffffu;
-        if (WHOLE) {
-          hit = true;
-          q = s0 + u;
-        } else {
-          bool maybe = true;
-          if (filter) {
-            const uint32_t h = ego_hash(c, u) & fmask;
-            maybe = (filter[h >> 5] >> (h & 31)) & 1u;
-          }
-          if (maybe) {
-            q = ego_find(mu, s0, s1, u);
-            hit = q < s1 && mu[q] == u;
-          }
-        }
-      }
-      const unsigned long long m = __ballot(hit);
-      if (PASS && hit) {
-        const int64_t o = base + total + __popcll(m & ((1ull << lane) - 1ull));
-        out_dst[o] = vid;                     // row v holds v's in-edges
-        out_src[o] = new_id(q, u);
-      }
-      total += (int)__popcll(m);
+    if (!PASS) {
+      if (lane == 0) cnt[p] = re - rs;
+      continue;
     }
-    if (!PASS && lane == 0) cnt[p] = total;
+    const int64_t vid = new_id(p, v), base = eoff[p];
+    if (lane == 0) {
+      orig[vid] = (int64_t)v;
+      if (ego_of) ego_of[vid] = (int32_t)c;
+    }
+    for (int j = rs + lane; j < re; j += kWave) {
+      const uint32_t u = (uint32_t)col[j] & 0x7fffffffu;
+      out_dst[base + (j - rs)] = vid;         // row v holds v's in-edges
+      out_src[base + (j - rs)] = new_id(s0 + u, u);
+    }
   }
 }
 
-
 // ---- the induced edges of the ego nets, one workgroup per (ego, chunk of its members) -----------------------------------
-// The wave-per-member kernel above tests every neighbour against a hash filter in L2: 1.1 * 10^8 random line reads per
-// pass at 4096 centres of a 10^7-node graph (4.2 ms per pass, latency-bound: member key -> row starts -> neighbour ids ->
-// filter word, one dependent round trip each).  An ego net is small (hundreds of members): its membership test belongs
-// in LDS.  A workgroup takes up to kEgoChunk consecutive members of ONE ego and
+// This round's first form — a wave per member testing every neighbour against a hash filter in L2, then a binary search
+// in the ego's segment — made 1.1 * 10^8 random line reads per pass at 4096 centres of a 10^7-node graph (4.2 ms per pass,
+// latency-bound: member key -> row starts -> neighbour ids -> filter word, one dependent round trip each).  An ego net is
+// small (hundreds of members): its membership test belongs in LDS.  A workgroup takes up to kEgoChunk consecutive members of ONE ego and
 //   * builds the ego's membership table in LDS — original id -> position, open addressing over kEgoTable slots — when
 //     the ego has at most kEgoList members (larger egos: every stride-th member in LDS, the search ends in global memory);
 //   * loads the row starts / ends of ITS members into LDS with all gathers in flight at once;
@@ -719,7 +665,7 @@ int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N, const in
   const bool want_csr = (flags & MP_EGO_CSR) != 0 && !whole;
   const bool loops = want_csr && (flags & MP_EGO_CSR_SELF_LOOPS) != 0;
   EGO_TAKE(mu, uint32_t, (size_t)M * 4);
-  hipLaunchKernelGGL(ego_index_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, members, M, mu, (uint32_t*)nullptr, 0u);
+  hipLaunchKernelGGL(ego_index_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, members, M, mu);
   EGO_LAUNCH_CHECK();
   EGO_TAKE(seg, int64_t, (size_t)(B + 1) * 8);
   hipLaunchKernelGGL(ego_seg_kernel, dim3((unsigned)ceil_div(B + 1, kBlock)), dim3(kBlock), 0, st, members, M, B, seg);
@@ -759,8 +705,8 @@ int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N, const in
   hipLaunchKernelGGL((ego_edges_chunk_kernel<PASS, kChunk, LOOPS>), cgrid, dim3(kEgoBlock), 0, st, rowptr, col, centres, B, \
                      mu, seg, chunk_off, wg_ego, __VA_ARGS__, rec, qc, wg_heavy)
   if (whole)
-    hipLaunchKernelGGL((ego_edges_kernel<0, true>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
-                       seg, (const uint32_t*)nullptr, 0u, cnt, eoff, nullptr, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((ego_edges_whole_kernel<0>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, cnt,
+                       eoff, nullptr, nullptr, nullptr, nullptr);
   else if (loops)
     EGO_CHUNK_LAUNCH(0, true, cnt, eoff, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr, (int32_t*)nullptr,
                      (int32_t*)nullptr, (int32_t*)nullptr);
@@ -799,8 +745,8 @@ int mp_ego_expand(const int32_t* rowptr, const int32_t* col, int64_t N, const in
     EGO_LAUNCH_CHECK();
   }
   if (whole)
-    hipLaunchKernelGGL((ego_edges_kernel<1, true>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M, mu,
-                       seg, (const uint32_t*)nullptr, 0u, nullptr, eoff, o_src, o_dst, o_orig, o_ego);
+    hipLaunchKernelGGL((ego_edges_whole_kernel<1>), egrid, dim3(kBlock), 0, st, rowptr, col, centres, B, N, members, M,
+                       nullptr, eoff, o_src, o_dst, o_orig, o_ego);
   else if (loops) {
     hipLaunchKernelGGL((ego_emit_light_kernel<true>), dim3(flat_grid(M)), dim3(kBlock), 0, st, members, M, B, seg, qc, cnt,
                        eoff, rec, o_src, o_dst, o_orig, o_ego, o_col, o_eid);
