@@ -68,6 +68,9 @@ PROTOTYPES = {
     "mp_agg_dense_add_f32": (C.c_int, [_p, _p, _p, _i64, C.c_int, _p, _i64, _i32, _p, _i64, C.c_float, _p, _i64, _i32, _p,
                                        C.c_int, _p, _p, _i64, _p, _i64, _p, _p, _i64, _p]),
     "mp_id_fixup_f32": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i32, C.c_int, _p]),
+    "mp_idgnn_agg_tiles_f32": (C.c_int, [_p, _p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p,
+                                         _i64, _p]),
+    "mp_id_rows_f32": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _p]),
     "mp_dense_fused_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _p, _p, C.c_int, _p, _i64, _i64, _i32, _i32, _p]),
     "mp_dense_x3_f32": (C.c_int, [_p, _i64, _p, _p, _i32, _p, _i64, _i64, _i32, _i32, _p]),
     "mp_split_w_bf16x3": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),

@@ -25,14 +25,14 @@ def _f32c(t, name):
 
 def _raw_spmm(g, x, reduce, S=None, self_scale=0.0, bias=None, relu=False, want_argmax=False,
               col_override=None, out=None):
-    """one launch of mp_spmm_csr_f32 — or, for plain sum / mean at d = 128 / 256 / 512 on a large operator, of
-    mp_agg_rows_tiles_f32 (the same aggregation on the producer/consumer tile structure: 2-5 % faster; MP_AGG_TILES=0
-    keeps the plan-based kernel) —; x [n_src, d] -> y [N, d] (written into `out` when given)"""
+    """one launch of mp_spmm_csr_f32 — or, for plain sum / mean / max (values only, no argmax) at d = 128 / 256 / 512 on
+    a large operator, of mp_agg_rows_tiles_f32 (the same aggregation on the producer/consumer tile structure: 2-5 %
+    faster; MP_AGG_TILES=0 keeps the plan-based kernel) —; x [n_src, d] -> y [N, d] (written into `out` when given)"""
     L = lib()
     N, d = g.num_nodes, x.size(1)
     y = out if out is not None else placement.empty_or_torch((N, d), x.device, reads=(x,))
-    if (reduce in (_lib.SUM, _lib.MEAN) and d in AGG_TILES_WIDTHS and N >= AGG_TILES_MIN_ROWS and bias is None and not relu
-            and not want_argmax and col_override is None and not (reduce == _lib.MEAN and S is not None)
+    if (reduce in (_lib.SUM, _lib.MEAN, _lib.MAX) and d in AGG_TILES_WIDTHS and N >= AGG_TILES_MIN_ROWS and bias is None
+            and not relu and not want_argmax and col_override is None and not (reduce != _lib.SUM and S is not None)
             and os.environ.get("MP_AGG_TILES", "1") != "0"
             and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0
             and (S is None or (S.stride(0) % 4 == 0 and S.data_ptr() % 16 == 0))
@@ -775,11 +775,27 @@ def _(dy, argmax, graph):
 def _op_idgnn_agg_raw(x: Tensor, graph: int, id_index: Tensor) -> Tuple[Tensor, Tensor]:
     g = from_handle(graph)
     x = _f32c(x, "x")
-    col_marked = g.mark_ids(id_index)
     L = lib()
     N, d = g.num_nodes, x.size(1)
     P = placement.empty_or_torch((N, d), x.device, reads=(x,))
     Q = placement.empty_or_torch((N, d), x.device, reads=(x,))
+    if (d in AGG_TILES_WIDTHS and N >= AGG_TILES_MIN_ROWS and os.environ.get("MP_AGG_TILES", "1") != "0"
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and g.nnz > 0 and id_index.numel() > 0
+            and g.max_row_entries() <= FUSED_MAX_ROW):
+        # the tile structure (round 4): P in the pass of mp_agg_rows_tiles_f32, which also writes the zero rows of Q;
+        # the rows of Q next to an identity node come from their few identity entries, gathered from x[id] by a small
+        # kernel the call launches behind the tile kernel
+        global AGG_TILES_CALLS
+        AGG_TILES_CALLS += 1
+        br = g.id_branch(id_index)
+        Z = x.index_select(0, id_index.to(torch.int64))
+        with torch.cuda.device(x.device):
+            check(L.mp_idgnn_agg_tiles_f32(ptr(g.rowptr), ptr(g.col), ptr(g.val), N, ptr(x), x.stride(0), d, ptr(br.defer),
+                                           ptr(br.rows), ptr(br.crp), ptr(br.slot), ptr(br.val), br.n_rows, ptr(Z),
+                                           Z.stride(0), ptr(P), P.stride(0), ptr(Q), Q.stride(0), _stream()),
+                  "mp_idgnn_agg_tiles_f32")
+        return P, Q
+    col_marked = g.mark_ids(id_index)
     plan, counts = g.plan()
     with torch.cuda.device(x.device):
         nb = C.c_size_t(0)
@@ -1016,7 +1032,12 @@ def spmm(g, x, reduce="sum", self_scale=0.0, bias=None, relu=False):
     reduce: 'sum'/'add' | 'mean' | 'max'.  The gradient flows to x and bias; entry values
     of g are constants here (attention weights go through spmm_edge_values)."""
     _require_hip(x, "x")
-    return torch.ops.mp.spmm(x, g.handle, _lib.REDUCE[reduce], float(self_scale), bias, bool(relu))[0]
+    r = _lib.REDUCE[reduce]
+    if r == _lib.MAX and not (torch.is_grad_enabled() and (x.requires_grad or (bias is not None and bias.requires_grad))):
+        # nothing will be differentiated: no argmax written (and the tile kernel may take the launch)
+        return torch.ops.mp.spmm_raw(x, g.handle, 0, r, x if self_scale != 0.0 else None, float(self_scale), bias,
+                                     bool(relu), False)[0]
+    return torch.ops.mp.spmm(x, g.handle, r, float(self_scale), bias, bool(relu))[0]
 
 
 @custom_op("mp::idgnn_agg", mutates_args=(), device_types="cuda")

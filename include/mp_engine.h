@@ -314,8 +314,9 @@ int mp_agg_dense_add_f32(const int32_t* rowptr, const int32_t* col, const float*
                          const float* R, int64_t ldr, mp_stream_t stream);
 
 /* The aggregation ALONE on the same workgroup structure (round 3): out[N, F] = reduce_j w_ij X[j] (+ self_scale * S) —
- * SparseAdj.matmul (sparse_adj.py:91-97), the same contract as mp_spmm_csr_f32 with reduce = MP_SUM | MP_MEAN and no
- * epilogue.  Four waves of a workgroup gather 64-row tiles into LDS while four others store the finished tile with
+ * SparseAdj.matmul (sparse_adj.py:91-97), the same contract as mp_spmm_csr_f32 with reduce = MP_SUM | MP_MEAN | MP_MAX
+ * (max: values only, S must be NULL, rows without entries are 0; bit for bit the rows of mp_spmm_csr_f32, whose argmax
+ * the backward pass uses) and no epilogue.  Four waves of a workgroup gather 64-row tiles into LDS while four others store the finished tile with
  * full-line non-temporal stores; tiles are drawn from a counter (no plan, no workspace).  F = 128, 256 or 512, 16-byte
  * aligned rows, rows of at most 2^18 stored entries (longer rows: mp_spmm_csr_f32, whose plan spreads them over many
  * waves); MP_ERR_UNSUPPORTED otherwise.  Faster than the plan-based kernel at these widths (19.6 against 20.6 ms at
@@ -334,6 +335,23 @@ int mp_agg_rows_tiles_f32(const int32_t* rowptr, const int32_t* col, const float
  * rows [n_rows] ascending row ids, crp [n_rows + 1], slot [crp[n_rows]] = row of Z, val NULL = ones. */
 int mp_id_fixup_f32(const int32_t* rows, const int32_t* crp, const int32_t* slot, const float* val, int64_t n_rows,
                     const float* Z, int64_t ldz, float* out, int64_t ldo, int32_t d, int act, mp_stream_t stream);
+
+/* The two-branch aggregation of gcn_id (TfgIDLayer.py:510-517; the contract of mp_idgnn_agg_f32: P = A X, Q = A S X
+ * with S selecting the identity nodes' rows) on the tile structure of mp_agg_rows_tiles_f32:
+ *   P = A X (col: plain or sign-marked indices) and, in the same pass, the rows of Q written as zeros — except the rows
+ *   with id_rows[r] != 0 (the rows that own an entry from an identity node), which a small kernel launched behind the
+ *   tile kernel writes as
+ *   Q[rows[k], :] = sum_{e in [crp[k], crp[k+1])} val_id[e] * Z[slot[e], :]  with Z = X[id]
+ *   (rows / crp / slot / val_id: as for mp_id_fixup_f32; id_rows [N] uint8 = 1 exactly on `rows`).
+ * Every row of Q is written exactly once; the identity entries (1 % of the operator at 1 % identity nodes) are gathered
+ * from an [n_id, F] matrix.  n_rows = 0: Q = 0.  F = 128, 256 or 512, 16-byte aligned rows; MP_ERR_UNSUPPORTED otherwise.
+ * mp_id_rows_f32 is the small kernel alone (the row's old contents are not read). */
+int mp_idgnn_agg_tiles_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, const float* X,
+                           int64_t ldx, int32_t F, const uint8_t* id_rows, const int32_t* rows, const int32_t* crp,
+                           const int32_t* slot, const float* val_id, int64_t n_rows, const float* Z, int64_t ldz, float* P,
+                           int64_t ldp, float* Q, int64_t ldq, mp_stream_t stream);
+int mp_id_rows_f32(const int32_t* rows, const int32_t* crp, const int32_t* slot, const float* val, int64_t n_rows,
+                   const float* Z, int64_t ldz, float* out, int64_t ldo, int32_t d, mp_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * Dense transform after the aggregation, fused (K10 / K11 / K15):       *

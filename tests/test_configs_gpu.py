@@ -321,22 +321,33 @@ def test_c5_d512_aggregation_and_two_branch_at_10m(dev, big_graph, monkeypatch):
     G = G0.gcn_norm("row")
     ids = torch.randperm(n, device=dev, generator=gen)[: n // 100]
     ids = torch.cat([torch.arange(0, 4, device=dev), ids[ids >= 4]])        # a few hubs among the identity nodes
-    P, Q = ops.idgnn_aggregate(G, ids, x)
-    monkeypatch.setenv("MP_AGG_TILES", "0")                      # the plan-based kernel, which the two-branch form shares
-    y_plan = ops.spmm(G, x, "sum")
-    assert torch.equal(P, y_plan)                                # the first branch IS the plain aggregation
-    del y_plan
-    monkeypatch.delenv("MP_AGG_TILES")
+    before = ops.AGG_TILES_CALLS
+    P, Q = ops.idgnn_aggregate(G, ids, x)                        # (at this size: the tile structure, round 4)
+    assert ops.AGG_TILES_CALLS == before + 1
     y = ops.spmm(G, x, "sum")                                    # (what the product dispatches at d = 512: the tile kernel)
+    assert torch.equal(P, y)                                     # the first branch IS the plain aggregation
     r64, r32, _ = _sampled_aggregate(G, x, rows, "sum")
     assert_close_rows(y[rows], r64, 1e-5, ref32=r32, what="C5 weighted sum, d=512")
-    del y, P
+    del y
+    monkeypatch.setenv("MP_AGG_TILES", "0")                      # the one-pass plan-based kernel: same branches
+    P0, Q0 = ops.idgnn_aggregate(G, ids, x)
+    assert ops.AGG_TILES_CALLS == before + 2                     # (only the plain aggregation above counted)
+    y_plan = ops.spmm(G, x, "sum")
+    assert torch.equal(P0, y_plan)
+    del y_plan
+    dP = (P - P0).abs().amax(1) / P0.abs().amax(1).clamp(min=1e-30)
+    assert float(dP.max()) < 1e-5                                # the order of a cut row's partial sums, nothing else
+    del P, P0, dP
     xm = torch.zeros_like(x)
     xm[ids] = x[ids]
-    monkeypatch.setenv("MP_AGG_TILES", "0")
     yq = ops.spmm(G, xm, "sum")                                  # A (S x) by the plain (plan-based) kernel
     monkeypatch.delenv("MP_AGG_TILES")
-    assert torch.equal(Q, yq)
+    assert torch.equal(Q0, yq)
+    del xm, Q0
+    assert torch.equal(Q == 0, yq == 0)                          # the same rows are zero, exactly
+    dQ = (Q - yq).abs().amax(1) / yq.abs().amax(1).clamp(min=1e-30)
+    assert float(dQ.max()) < 1e-5
+    del yq, dQ
     is_id = torch.zeros(n, dtype=torch.bool, device=dev)
     is_id[ids] = True
     seg, col, val, _ = _sampled_entries(G, rows)

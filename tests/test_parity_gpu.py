@@ -848,3 +848,109 @@ def test_tile_aggregation_matches_oracle_and_the_plan_kernel(dev, monkeypatch, n
     diff = (y1 - y0).abs().amax(dim=1)
     scale = y0.abs().amax(dim=1).clamp(min=1e-30)
     assert float((diff / scale).max()) < 1e-5
+
+
+@pytest.mark.parametrize("n,E,d,weighted,hubs", [
+    (5000, 60_000, 256, True, False), (70_001, 300_000, 256, False, True), (4097, 3000, 128, True, False),
+    (20_000, 200_000, 512, True, True), (64, 0, 256, False, False), (1000, 1, 128, False, False),
+])
+def test_tile_max_equals_the_plan_kernel_bit_for_bit(dev, monkeypatch, n, E, d, weighted, hubs):
+    """reduce = max on the tile structure (mp_agg_rows_tiles_f32, values only — what ops.spmm dispatches when nothing is
+    differentiated): a maximum does not depend on the order of its terms, so the rows equal the plan-based kernel's bit
+    for bit (whose argmax the backward pass keeps using), rows without entries are 0 (generalconv.py:18 'max' through
+    scatter's fill), and every value is the float32 maximum of w_ij * x[j] exactly."""
+    import graphgym_amd as ga
+    from graphgym_amd import ops, _lib
+    g = torch.Generator().manual_seed(n + d + 1)
+    dst = torch.randint(0, n, (E,), generator=g)
+    src = torch.randint(0, n, (E,), generator=g)
+    if hubs:
+        k = E // 3
+        dst[:k] = torch.randint(0, 4, (k,), generator=g) * 1000 + 17
+    ei = torch.stack([dst, src])
+    w = (torch.rand(E, generator=g) + 0.1) if weighted else None
+    x = torch.randn(n, d, generator=g) - 1.5                   # mostly negative: an empty row (0) differs from any maximum
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, None if w is None else w.to(dev), dst_row=0)
+    xd = x.to(dev)
+    monkeypatch.setenv("MP_AGG_TILES", "1")
+    monkeypatch.setattr(ops, "AGG_TILES_MIN_ROWS", 1)
+    before = ops.AGG_TILES_CALLS
+    with torch.no_grad():
+        y1 = ops.spmm(G, xd, "max")
+    want_calls = before + (1 if E > 0 else 0)                  # (an operator without entries stays with the plan kernel)
+    assert ops.AGG_TILES_CALLS == want_calls
+    y0, arg = ops._raw_spmm(G, xd, _lib.MAX, want_argmax=True)
+    assert ops.AGG_TILES_CALLS == want_calls                    # an argmax is the plan-based kernel's
+    assert torch.equal(y1, y0)
+    msg = x[src] * (w[:, None] if weighted else 1.0)
+    want = torch.zeros(n, d).scatter_reduce(0, dst[:, None].expand(E, d), msg, "amax", include_self=False) if E else \
+        torch.zeros(n, d)
+    assert torch.equal(y1.cpu(), want)
+    # differentiated: the registered operator, argmax and all
+    xg = xd.clone().requires_grad_(True)
+    y2 = ops.spmm(G, xg, "max")
+    assert ops.AGG_TILES_CALLS == want_calls and torch.equal(y2.detach(), y0)
+
+
+@pytest.mark.parametrize("n,E,d,weighted,hubs,n_id", [
+    (70_001, 600_000, 256, True, True, 700), (66_000, 400_000, 256, False, False, 3000), (65_536, 500_000, 512, True, True, 650),
+    (80_003, 300_000, 128, True, False, 1), (4100, 9000, 256, False, False, 4100),
+])
+def test_two_branch_aggregation_on_the_tile_structure(dev, monkeypatch, n, E, d, weighted, hubs, n_id):
+    """(P, Q) = (A x, A S x) (gcn_id, TfgIDLayer.py:510-517) as ops.idgnn_aggregate dispatches it from 2^21 rows at
+    d = 128 / 256 / 512: P in the pass of the tile kernel, which also writes the zero rows of Q; the rows of Q next to an
+    identity node by mp_id_rows_f32.  Against the float64 oracle, against the one-pass plan-based kernel, P bit-equal to
+    the plain tile aggregation, Q exactly zero off the identity nodes' neighbours, gradients through both branches."""
+    import graphgym_amd as ga
+    from graphgym_amd import ops, _lib
+    g = torch.Generator().manual_seed(n + d + 2)
+    dst = torch.randint(0, n, (E,), generator=g)
+    src = torch.randint(0, n, (E,), generator=g)
+    if hubs:
+        k = E // 3
+        dst[:k] = torch.randint(0, 4, (k,), generator=g) * 1000 + 17
+        src[k:2 * k] = torch.randint(0, 4, (k,), generator=g) * 1000 + 17     # hubs as sources: identity entries in many rows
+    ei = torch.stack([dst, src])
+    w = (torch.rand(E, generator=g) + 0.1) if weighted else None
+    x = torch.randn(n, d, generator=g)
+    ids = torch.randperm(n, generator=g)[:n_id]
+    if hubs:
+        ids[:2] = torch.tensor([17, 1017])
+        ids = torch.unique(ids)
+    G = ga.CSRGraph.from_edge_index(ei.to(dev), n, None if w is None else w.to(dev), dst_row=0)
+    xd, idd = x.to(dev), ids.to(dev)
+    monkeypatch.setenv("MP_AGG_TILES", "1")
+    monkeypatch.setattr(ops, "AGG_TILES_MIN_ROWS", 1)
+    before = ops.AGG_TILES_CALLS
+    xg = xd.clone().requires_grad_(True)
+    P, Q = ops.idgnn_aggregate(G, idd, xg)
+    assert ops.AGG_TILES_CALLS == before + 1
+    dP, dQ = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+    (P * dP.to(dev) + Q * dQ.to(dev)).sum().backward()
+    P, Q = P.detach(), Q.detach()
+    before = ops.AGG_TILES_CALLS                                 # (the backward pass aggregated on tiles too)
+    P2, Q2 = ops.idgnn_aggregate(G, idd, xd)
+    assert torch.equal(P, P2) and torch.equal(Q, Q2)             # reproducible
+    y, _ = ops._raw_spmm(G, xd, _lib.SUM)
+    assert ops.AGG_TILES_CALLS == before + 2 and torch.equal(P, y)
+    monkeypatch.setenv("MP_AGG_TILES", "0")
+    P0, Q0 = ops.idgnn_aggregate(G, idd, xd)
+    assert ops.AGG_TILES_CALLS == before + 2                     # ... and this was the plan-based kernel
+    sel = torch.zeros(n, 1)
+    sel[ids] = 1
+
+    def ref(c):
+        xr = c(x).clone().requires_grad_(True)
+        adj = R.SparseAdj(ei, None if w is None else c(w), [n, n])
+        Pr, Qr = adj @ xr, adj @ (xr * c(sel))
+        (Pr * c(dP) + Qr * c(dQ)).sum().backward()
+        return Pr.detach(), Qr.detach(), xr.grad
+    r64, r32 = both(ref)
+    close(P, (r64[0], r32[0]), what="tile two-branch P")
+    close(Q, (r64[1], r32[1]), what="tile two-branch Q")
+    close(xg.grad, (r64[2], r32[2]), what="tile two-branch dx")
+    close(P0, (r64[0], r32[0]), what="plan two-branch P")
+    close(Q0, (r64[1], r32[1]), what="plan two-branch Q")
+    has = torch.zeros(n).index_add_(0, dst, sel[src].view(-1)) > 0
+    assert float(Q.cpu()[~has].abs().max()) == 0.0 if bool((~has).any()) else True
+    assert torch.equal(Q == 0, Q0 == 0)
