@@ -63,7 +63,7 @@ y = placement.empty_or_torch((n, d), dev, reads=(x,))
 agg_bytes = (nnz * (d * 4 + 8) + n * (d * 4 + 4)) / 1e9
 for red, name in ((0, "sum"), (1, "mean"), (2, "max")):
     t = timeit(lambda: ops._raw_spmm(g, x, red, out=y, want_argmax=False))
-    rec(f"agg_rows {name} (weighted)", t, agg_bytes)
+    rec(f"agg_rows {name} (weighted; tile structure)", t, agg_bytes)
 t = timeit(lambda: ops._raw_spmm(gt, x, 0, out=y))
 rec("agg_rows sum on the transposed operator (backward)", t, agg_bytes)
 t = timeit(lambda: ops._raw_spmm(g, x, 0, S=x, self_scale=1.0, out=y))
@@ -71,7 +71,7 @@ rec("agg_rows sum + self term (GIN combine)", t, agg_bytes + n * d * 4 / 1e9)
 ids = torch.arange(0, n, 100, device=dev)
 with torch.no_grad():
     t_two = timeit(lambda: ops.idgnn_aggregate(g, ids, x))
-rec("agg_rows two-branch (P and Q in one pass, 1 % identity nodes)", t_two, agg_bytes + n * d * 4 / 1e9)
+rec("agg_rows two-branch (P, Q; tile structure + identity rows, 1 % identity nodes)", t_two, agg_bytes + n * d * 4 / 1e9)
 # attention pieces
 s = None
 t = timeit(lambda: ops._raw_sddmm_dot(g, x, x, 1, 1.0))
@@ -120,7 +120,11 @@ with torch.no_grad():
     def id_two_kernels():
         P, Q = ops.idgnn_aggregate(g, ids, x)
         return ops.dense_fused(P, W, Q, Wid, b, relu=True)
-    t_id2 = timeit(id_two_kernels)
+    st0 = dict(placement.stats())
+    t_id2 = timeit(id_two_kernels, iters=5, warm=4)
+    st1 = placement.stats()
+    print(json.dumps({"placement_during_round1_form": {k: st1[k] - st0[k] for k in ("allocations", "probed_pairs", "searches", "retries")
+                                                       if isinstance(st1.get(k), (int, float))}}), flush=True)
 rec("ID-GCN layer, one-kernel form (agg_dense + identity fix-up)", t_id, agg_bytes, tflop=2.0 * n * d * d / 1e12,
     note="round 1's form below: two-branch aggregation + dual GEMM")
 rec("ID-GCN layer, round-1 form (two-branch aggregation, then P W + Q W_id)", t_id2, agg_bytes + 3 * n * d * 4 / 1e9, tflop=4.0 * n * d * d / 1e12)
@@ -165,6 +169,30 @@ del out, up, xr
 u = torch.rand(ids.numel(), d, device=dev)
 t = timeit(lambda: ops.gather_rows(x, ids))
 rec("rows_gather (identity rows)", t, 2 * ids.numel() * d * 4 / 1e9, note="10^5 rows: launch / latency-bound")
+del u
+torch.cuda.empty_cache()
+# per-batch graph work at the size of a training step's batch (6 * 10^6 stored entries): the general build, and what an
+# ego batch pays instead (the expansion writes the CSR; symmetric: no transpose)
+nb = 600_000
+eb = graphgen.ba_edge_index(nb, 5, 7, device=dev)
+def build_b():
+    return CSRGraph.from_edge_index(eb, nb, add_self_loops=True)
+t_b = timeit(build_b, iters=5, warm=2)
+gb_ = build_b()
+rec("batch-size csr_from_coo + self loops (6.6e6 entries)", t_b, (eb.size(1) + nb) * 24 * 2 / 1e9, note="general batches; sort-bound")
+def tr_b():
+    gb_._t = None
+    return gb_._transpose_sorted() if hasattr(gb_, "_transpose_sorted") else gb_.transpose()
+rec("batch-size csr_transpose", timeit(tr_b, iters=5, warm=2), gb_.nnz * 24 * 2 / 1e9)
+rec("batch-size gcn_norm", timeit(lambda: gb_.gcn_norm(), iters=5, warm=2), (gb_.nnz * 20 + nb * 16) / 1e9)
+from graphgym_amd.ego import ego_batch
+base = CSRGraph.from_edge_index(graphgen.ba_edge_index(2_000_000, 5, 11, device=dev), 2_000_000)
+cen = torch.randint(0, 2_000_000, (4096,), device=dev)
+t_e = timeit(lambda: ego_batch(base, cen, 2, csr="add"), iters=5, warm=2)
+eg = ego_batch(base, cen, 2, csr="add")
+rec("ego batch: expansion + its CSR with self loops (4096 centres, radius 2, base 2e6 nodes)", t_e,
+    note=f"{eg[1].numel()} nodes, {eg[4].nnz} stored entries; replaces sampler + csr_from_coo + transpose for ego batches")
+rec("ego batch: gcn_norm of the expansion's CSR", timeit(lambda: eg[4].gcn_norm("row"), iters=5, warm=2), (eg[4].nnz * 20 + eg[1].numel() * 16) / 1e9)
 print("\n| kernel | ms | algorithmic GB | GB/s | % of 8 TB/s | TFLOP/s | % of 157 TF | note |\n|---|---|---|---|---|---|---|---|")
 for r in rows:
     print(f"| {r['kernel']} | {r['ms']} | {r.get('algorithmic_GB', '')} | {r.get('GBps', '')} | "
