@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "libmp
 MP_OK = 0
 SUM, MEAN, MAX = 0, 1, 2
 REDUCE = {"sum": SUM, "add": SUM, "mean": MEAN, "max": MAX}
-COO_REMOVE_SELF_LOOPS, COO_ADD_SELF_LOOPS, COO_KEEP_LOOP_WEIGHT = 1, 2, 4
+COO_REMOVE_SELF_LOOPS, COO_ADD_SELF_LOOPS, COO_KEEP_LOOP_WEIGHT, COO_RECT = 1, 2, 4, 8
 AXIS_ROW, AXIS_COL = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
 
@@ -38,6 +38,7 @@ PROTOTYPES = {
     "mp_csr_from_coo": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _f32, _p, _p, _p, _p, _p, _sz, _p]),
     "mp_check_edge_index": (C.c_int, [_p, _p, _i64, _i64, _p, _p]),
     "mp_csr_row_ids": (C.c_int, [_p, _i64, _i64, _p, _p]),
+    "mp_csr_is_symmetric": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "mp_csr_transpose_ws_bytes": (C.c_int, [_i64, _i64, _psz]),
     "mp_csr_transpose": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "mp_csr_degree": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _p, _p]),

@@ -14,10 +14,10 @@
 
 namespace mp {
 
-static int key_bits(int64_t N) {
+static int id_bits(int64_t N) {
   int b = 1;
   while (((int64_t)1 << b) <= N) ++b;  // ids 0..N need b bits (N itself marks "removed")
-  return 32 + b;
+  return b;
 }
 
 struct CooWs {
@@ -53,11 +53,12 @@ __global__ __launch_bounds__(kBlock) void fill_f32_kernel(float* p, int64_t n, f
        i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
-// key = dst << 32 | src ; removed self loops get row N (sorts behind every real row)
+// key = dst << shift | src, shift = id_bits(N): the sort then runs over 2 * shift bits instead of 32 + shift (N = 6e5:
+// 40 bits, five 8-bit passes instead of seven); removed self loops get row N (sorts behind every real row)
 __global__ __launch_bounds__(kBlock) void coo_keys_kernel(const int64_t* __restrict__ dst,
                                                           const int64_t* __restrict__ src,
                                                           const float* __restrict__ w, int64_t E,
-                                                          int64_t N, int flags, uint64_t* keys,
+                                                          int64_t N, int flags, int shift, uint64_t* keys,
                                                           uint32_t* pay, float* loop_w) {
   const bool rm = flags & MP_COO_REMOVE_SELF_LOOPS;
   const bool add = flags & MP_COO_ADD_SELF_LOOPS;
@@ -69,27 +70,27 @@ __global__ __launch_bounds__(kBlock) void coo_keys_kernel(const int64_t* __restr
     if (i < E) {
       const int64_t d = dst[i], s = src[i];
       if (rm && d == s) {
-        key = (uint64_t)N << 32;
+        key = (uint64_t)N << shift;
         if (keep) loop_w[d] = w ? w[i] : 1.f;  // an existing loop's weight survives (last one wins)
       } else {
-        key = ((uint64_t)d << 32) | (uint64_t)(uint32_t)s;
+        key = ((uint64_t)d << shift) | (uint64_t)(uint32_t)s;
       }
     } else {
       const uint64_t n = (uint64_t)(i - E);
-      key = (n << 32) | n;
+      key = (n << shift) | n;
     }
     keys[i] = key;
     pay[i] = (uint32_t)i;
   }
 }
 
-// rowptr[r] = first sorted position whose key >= r << 32, r = 0..N
+// rowptr[r] = first sorted position whose key >= r << shift, r = 0..N
 __global__ __launch_bounds__(kBlock) void rowptr_from_keys_kernel(const uint64_t* __restrict__ keys,
-                                                                  int64_t M, int64_t N,
+                                                                  int64_t M, int64_t N, int shift,
                                                                   int32_t* rowptr) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= N;
        r += (int64_t)gridDim.x * blockDim.x) {
-    const uint64_t target = (uint64_t)r << 32;
+    const uint64_t target = (uint64_t)r << shift;
     int64_t lo = 0, hi = M;
     while (lo < hi) {
       const int64_t mid = lo + ((hi - lo) >> 1);
@@ -104,14 +105,14 @@ __global__ __launch_bounds__(kBlock) void coo_emit_kernel(const uint64_t* __rest
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ loop_w,
                                                           int64_t M, int64_t E, int64_t N, float fill,
-                                                          int keep, int32_t* col, float* val,
+                                                          int keep, int shift, int32_t* col, float* val,
                                                           int32_t* eid) {
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < M;
        k += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t key = keys[k];
-    if ((int64_t)(key >> 32) >= N) continue;  // removed entry
+    if ((int64_t)(key >> shift) >= N) continue;  // removed entry
     const uint32_t p = pay[k];
-    col[k] = (int32_t)(uint32_t)key;
+    col[k] = (int32_t)(uint32_t)(key & (((uint64_t)1 << shift) - 1));
     if ((int64_t)p < E) {
       if (val) val[k] = w ? w[p] : 1.f;
       if (eid) eid[k] = (int32_t)p;
@@ -200,6 +201,30 @@ __global__ __launch_bounds__(kBlock) void transpose_keys_kernel(const int32_t* _
     keys[e] = ((uint64_t)(uint32_t)col[e] << 32) | (uint64_t)(uint32_t)r;
     pay[e] = (uint32_t)e;
   });
+}
+
+// Is the stored operator its own transpose?  Every entry (r, c, v) looks for (c, r) in row c (columns ascend within a
+// row: binary search) and compares the values bit for bit; a repeated (r, c) counts as "no" (A[r, c] is then a sum the
+// search cannot see).  flag[0] is set to 1 by any entry that fails.
+__global__ __launch_bounds__(kBlock) void csr_symmetric_kernel(const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ col,
+                                                               const float* __restrict__ val, int32_t N, int64_t nnz,
+                                                               int32_t* flag) {
+  bool bad = false;
+  for_entries_with_rows(rowptr, N, nnz, [&](int64_t e, int r) {
+    const int c = col[e];
+    if ((unsigned)c >= (unsigned)N) { bad = true; return; }   // (not a square operator)
+    if (e + 1 < rowptr[r + 1] && col[e + 1] == c) bad = true;
+    if (c == r) return;
+    int lo = rowptr[c], hi = rowptr[c + 1];
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      if (col[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= rowptr[c + 1] || col[lo] != r) { bad = true; return; }
+    if (val && __float_as_uint(val[lo]) != __float_as_uint(val[e])) bad = true;
+  });
+  if (bad) flag[0] = 1;
 }
 
 __global__ __launch_bounds__(kBlock) void transpose_emit_kernel(const uint64_t* __restrict__ keys,
@@ -366,7 +391,8 @@ int mp_csr_from_coo(const int64_t* dst, const int64_t* src, const float* w, int6
                     void* ws, size_t ws_bytes, mp_stream_t stream) {
   if (E < 0 || N < 0 || !rowptr || (E > 0 && (!dst || !src))) return MP_ERR_INVALID_ARG;
   if (E + N >= INT32_MAX) return MP_ERR_UNSUPPORTED;
-  if (flags & ~7) return MP_ERR_INVALID_ARG;
+  if (flags & ~15) return MP_ERR_INVALID_ARG;
+  if ((flags & MP_COO_RECT) && (flags & (MP_COO_REMOVE_SELF_LOOPS | MP_COO_ADD_SELF_LOOPS))) return MP_ERR_INVALID_ARG;
   const bool add = flags & MP_COO_ADD_SELF_LOOPS;
   const bool keep = (flags & MP_COO_KEEP_LOOP_WEIGHT) && (flags & MP_COO_REMOVE_SELF_LOOPS) && add;
   const int64_t M = E + (add ? N : 0);
@@ -386,18 +412,19 @@ int mp_csr_from_coo(const int64_t* dst, const int64_t* src, const float* w, int6
     hipLaunchKernelGGL(fill_f32_kernel, dim3(flat_grid(N)), dim3(kBlock), 0, st, L.loop_w, N, fill);
     MP_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(coo_keys_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, dst, src, w, E, N, flags,
+  const int shift = (flags & MP_COO_RECT) ? 32 : id_bits(N);
+  hipLaunchKernelGGL(coo_keys_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, dst, src, w, E, N, flags, shift,
                      L.keys_a, L.pay_a, L.loop_w);
   MP_LAUNCH_CHECK();
   rocprim::double_buffer<uint64_t> dk(L.keys_a, L.keys_b);
   rocprim::double_buffer<uint32_t> dv(L.pay_a, L.pay_b);
   size_t cub_bytes = L.cub_bytes;
-  MP_HIP(rocprim::radix_sort_pairs(L.cub, cub_bytes, dk, dv, (size_t)M, 0u, (unsigned)key_bits(N), st));
+  MP_HIP(rocprim::radix_sort_pairs(L.cub, cub_bytes, dk, dv, (size_t)M, 0u, (unsigned)(shift + id_bits(N)), st));
   hipLaunchKernelGGL(rowptr_from_keys_kernel, dim3(flat_grid(N + 1)), dim3(kBlock), 0, st, dk.current(),
-                     M, N, rowptr);
+                     M, N, shift, rowptr);
   MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(coo_emit_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, dk.current(), dv.current(),
-                     w, L.loop_w, M, E, N, fill, keep ? 1 : 0, col, val, eid);
+                     w, L.loop_w, M, E, N, fill, keep ? 1 : 0, shift, col, val, eid);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -418,6 +445,19 @@ int mp_csr_row_ids(const int32_t* rowptr, int64_t N, int64_t nnz, int32_t* row_o
   if (nnz == 0) return MP_OK;
   hipLaunchKernelGGL(row_ids_kernel, dim3(flat_grid(ceil_div(nnz, kRowTile) * kBlock)), dim3(kBlock), 0, as_stream(stream), rowptr,
                      (int32_t)N, nnz, row_of);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+int mp_csr_is_symmetric(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int64_t nnz,
+                        int32_t* flag, mp_stream_t stream) {
+  if (!rowptr || !flag || N < 0 || nnz < 0 || (nnz > 0 && !col)) return MP_ERR_INVALID_ARG;
+  if (nnz >= INT32_MAX || N >= INT32_MAX) return MP_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  MP_HIP(hipMemsetAsync(flag, 0, 4, st));
+  if (nnz == 0) return MP_OK;
+  hipLaunchKernelGGL(csr_symmetric_kernel, dim3(flat_grid(ceil_div(nnz, kRowTile) * kBlock)), dim3(kBlock), 0, st, rowptr, col,
+                     val, (int32_t)N, nnz, flag);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -454,9 +494,11 @@ int mp_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val
   rocprim::double_buffer<uint64_t> dk(L.keys_a, L.keys_b);
   rocprim::double_buffer<uint32_t> dv(L.pay_a, L.pay_b);
   size_t cub_bytes = L.cub_bytes;
-  MP_HIP(rocprim::radix_sort_pairs(L.cub, cub_bytes, dk, dv, (size_t)nnz, 0u, (unsigned)key_bits(N), st));
+  // the entries arrive in (row, column) order and the sort is stable: sorting on the column bits alone leaves the rows of
+  // a column ascending — 20 bits at 6e5 columns (three passes) instead of 52 (seven)
+  MP_HIP(rocprim::radix_sort_pairs(L.cub, cub_bytes, dk, dv, (size_t)nnz, 32u, (unsigned)(32 + id_bits(N)), st));
   hipLaunchKernelGGL(rowptr_from_keys_kernel, dim3(flat_grid(N + 1)), dim3(kBlock), 0, st, dk.current(),
-                     nnz, N, t_rowptr);
+                     nnz, N, 32, t_rowptr);
   MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(transpose_emit_kernel, dim3(flat_grid(nnz)), dim3(kBlock), 0, st, dk.current(),
                      dv.current(), val, nnz, t_col, t_val, pos);

@@ -11,6 +11,7 @@ Row r holds the in-edges of destination r; ``col`` holds source ids.
 import collections
 import ctypes as C
 import itertools
+import os
 import threading
 import weakref
 
@@ -104,6 +105,8 @@ class CSRGraph:
             NC = N if num_cols is None else int(num_cols)
             if NC != N and (remove_self_loops or add_self_loops):
                 raise ValueError("self-loop edits need a square operator")
+            if NC != N:
+                flags |= _lib.COO_RECT            # column ids beyond the row count: the wide sort key
             if validate:
                 bad = torch.zeros(2, dtype=torch.int32, device=dev)
                 check(L.mp_check_edge_index(ptr(dst), ptr(dst), E, N, ptr(bad[0:1]), _stream()))
@@ -243,9 +246,38 @@ class CSRGraph:
         """CSR of A^T (rows = sources) with values permuted; cached.  Graphs that share a sparsity
         pattern (with_values / gcn_norm) share one sorted transpose pattern and only permute values.
         A graph flagged `symmetric` is its own transpose."""
-        if self.symmetric:
+        if self.symmetric or (self._t is None and self.is_symmetric()):
             return self
         return self._transpose_sorted()
+
+    def is_symmetric(self, run=None):
+        """Does the stored operator equal its transpose, bit for bit?  Graphs flagged by their builder (ego batches) say
+        yes at once.  run=True (or MP_SYM_CHECK=1 for every transpose() call) runs mp_csr_is_symmetric — one binary
+        search per entry + one host read, cached; the reference's graphs are undirected, both directions stored
+        (loader.py, transform.py:11-38), so the answer is usually yes and the backward pass then needs no second CSR.
+        Off by default: the check costs what the sorted transpose costs (0.33 vs 0.33 ms at 6.6e6 entries, 8.8 vs 6.8 ms
+        at 1.1e8 — random probes against three radix passes), so it buys memory (12 B per entry), not time."""
+        if self.symmetric:
+            return True
+        known = self.__dict__.get("_sym_known")
+        if known is None:
+            known = False
+            if run is None:
+                run = os.environ.get("MP_SYM_CHECK", "0") == "1"
+            if not run:
+                return False                      # (not cached: a later explicit check may still run)
+            if self.num_nodes == self.num_cols and self.nnz > 0:
+                L = lib()
+                _built("is_symmetric")
+                flag = torch.empty(1, dtype=torch.int32, device=self.device)
+                with torch.cuda.device(self.device):
+                    check(L.mp_csr_is_symmetric(ptr(self.rowptr), ptr(self.col), ptr(self.val), self.num_nodes, self.nnz,
+                                                ptr(flag), _stream()), "mp_csr_is_symmetric")
+                known = int(flag.item()) == 0
+            self.__dict__["_sym_known"] = known
+            if known:
+                self.symmetric = True
+        return known
 
     def _transpose_sorted(self):
         if self._t is None:
@@ -380,7 +412,7 @@ class CSRGraph:
         g = self.with_values(val_out[:nnz])
         g.dinv = dinv[:N]
         # D^-1/2 A D^-1/2 of a symmetric operator with the row degrees (= column degrees) on both sides is symmetric
-        g.symmetric = self.symmetric
+        g.symmetric = self.is_symmetric()
         return g
 
     def scaled(self, row_scale=None, col_scale=None):

@@ -549,7 +549,7 @@ class _SddmmDot(torch.autograd.Function):
         # dQ[i, slice h] = sum_e ds[e,h] K[col_e, slice h]   (an aggregation over in-edges)
         dQ = _raw_spmm_heads(g, ds, K, heads)
         # dK[j, slice h] = sum_{e: col_e = j} ds[e,h] Q[row_e, slice h]   (over out-edges)
-        gt = g.transpose()
+        gt = g._transpose_sorted()     # (per-entry values are permuted through gt.pos: also when A^T = A)
         dK = _raw_spmm_heads(gt, ds[gt.pos.long()].contiguous(), Q, heads)
         return dQ, dK, None, None, None
 
@@ -677,7 +677,7 @@ class _SpmmEdgeValues(torch.autograd.Function):
         g, heads = ctx.g, ctx.heads
         dy = dy.contiguous()
         da = _raw_sddmm_dot(g, dy, V, heads, 1.0)
-        gt = g.transpose()
+        gt = g._transpose_sorted()     # (per-entry values are permuted through gt.pos: also when A^T = A)
         dV = _raw_spmm_heads(gt, a[gt.pos.long()].contiguous(), dy, heads)
         return da, dV, None, None
 

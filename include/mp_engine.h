@@ -50,8 +50,12 @@ enum mp_coo_flags {
   MP_COO_ADD_SELF_LOOPS = 2,    /* append one (i,i) entry per node: tfg add_self_loop_edge via
                                    SparseAdj.add_self_loop (sparse_adj.py:58-63, TfgIDLayer.py:298,547);
                                    PyG add_self_loops (idconv.py:303) */
-  MP_COO_KEEP_LOOP_WEIGHT = 4   /* with REMOVE|ADD: an existing loop's weight replaces `fill` for
+  MP_COO_KEEP_LOOP_WEIGHT = 4,  /* with REMOVE|ADD: an existing loop's weight replaces `fill` for
                                    that node = PyG add_remaining_self_loops (idconv.py:52-53,140-141,232-233) */
+  MP_COO_RECT = 8               /* a rectangular operator (pooling.py:12-33: rows = graphs, columns = nodes): src ids
+                                   may be any value below 2^32, not only [0, N).  Without it both ids share
+                                   id_bits(N) bits of the sort key and the sort runs over twice that (N = 6e5: 40
+                                   bits instead of 52); not with the self-loop flags */
 };
 
 /* degree axis for mp_csr_degree / mp_gcn_norm_edges */
@@ -107,7 +111,7 @@ int mp_probe_gather_ms(const void* src, size_t src_bytes, void* dst, size_t dst_
 int mp_csr_from_coo_ws_bytes(int64_t E, int64_t N, size_t* bytes_host);
 
 /*
- * dst/src: [E] int64 node ids in [0,N).  w: [E] fp32 or NULL (= all ones).
+ * dst/src: [E] int64 node ids in [0,N) (src: any id below 2^32 with MP_COO_RECT).  w: [E] fp32 or NULL (= all ones).
  * Outputs (capacity E+N entries each; nnz = rowptr[N] afterwards):
  *   rowptr [N+1] int32, col [cap] int32 (sorted by (row, col, input order)),
  *   val [cap] fp32 (may be NULL when w == NULL and fill == 1: unweighted),
@@ -128,6 +132,13 @@ int mp_check_edge_index(const int64_t* dst, const int64_t* src, int64_t E,
 /* row id of every stored entry: row_of[e] = r for rowptr[r] <= e < rowptr[r+1] */
 int mp_csr_row_ids(const int32_t* rowptr, int64_t N, int64_t nnz,
                    int32_t* row_of, mp_stream_t stream);
+
+/* flag[0] (device) = 0 if the stored square operator equals its transpose — every entry (r, c, v) has its mirror
+ * (c, r, v) with the same bits and no (r, c) is stored twice — else 1.  The undirected graphs of the reference's
+ * datasets (both directions stored, loader.py / transform.py:11-38) are their own transpose: the backward pass
+ * dL/dX = A^T dL/dY then needs no second CSR (mp_csr_transpose: a sort of all entries). */
+int mp_csr_is_symmetric(const int32_t* rowptr, const int32_t* col, const float* val, int64_t N, int64_t nnz,
+                        int32_t* flag, mp_stream_t stream);
 
 /*
  * Transpose (CSR of A^T, i.e. out-edges by source) for the backward pass

@@ -47,10 +47,21 @@ t = timeit(lambda: g0.gcn_norm())
 rec("gcn_norm = degree + inv_sqrt + norm_edges", t, (nnz * 4 + n * 8 + nnz * 16 + n * 8) / 1e9, note="dinv[col] is a random 4-byte gather per entry")
 def tr():
     g._t = None
-    return g.transpose()
+    src = getattr(g, "_pattern_of", None)
+    if src is not None:
+        src._t = None
+    return g._transpose_sorted()
 t_tr = timeit(tr, iters=3, warm=1)
-gt = g.transpose()
-rec("csr_transpose (keys, radix sort, emit; once per graph)", t_tr, nnz * 24 * 2 / 1e9, note="pattern shared with the un-normalised graph: values permuted only")
+gt = g._transpose_sorted()
+rec("csr_transpose (keys, radix sort on the column bits, emit; only for operators that are not symmetric)", t_tr, nnz * 24 * 2 / 1e9, note="pattern shared with the un-normalised graph: values permuted only")
+def sym():
+    g.__dict__.pop("_sym_known", None)
+    g.symmetric = False
+    return g.is_symmetric(run=True)
+t_sym = timeit(sym, iters=3, warm=1)
+rec("is_symmetric (one binary search per entry + one host read; once per graph)", t_sym, nnz * 12 / 1e9, note=f"-> {g.is_symmetric(run=True)}; opt-in (MP_SYM_CHECK=1): it costs what the sorted transpose costs")
+g.__dict__.pop("_sym_known", None)      # (the rest of the table runs as the default does: nobody asked)
+g.symmetric = False
 def pl():
     g._plan = None
     return g.plan()
@@ -182,8 +193,15 @@ gb_ = build_b()
 rec("batch-size csr_from_coo + self loops (6.6e6 entries)", t_b, (eb.size(1) + nb) * 24 * 2 / 1e9, note="general batches; sort-bound")
 def tr_b():
     gb_._t = None
-    return gb_._transpose_sorted() if hasattr(gb_, "_transpose_sorted") else gb_.transpose()
+    return gb_._transpose_sorted()
 rec("batch-size csr_transpose", timeit(tr_b, iters=5, warm=2), gb_.nnz * 24 * 2 / 1e9)
+def sym_b():
+    gb_.__dict__.pop("_sym_known", None)
+    gb_.symmetric = False
+    return gb_.is_symmetric(run=True)
+rec("batch-size is_symmetric", timeit(sym_b, iters=5, warm=2), gb_.nnz * 12 / 1e9, note=f"-> {gb_.is_symmetric(run=True)}")
+gb_.__dict__.pop("_sym_known", None)
+gb_.symmetric = False
 rec("batch-size gcn_norm", timeit(lambda: gb_.gcn_norm(), iters=5, warm=2), (gb_.nnz * 20 + nb * 16) / 1e9)
 from graphgym_amd.ego import ego_batch
 base = CSRGraph.from_edge_index(graphgen.ba_edge_index(2_000_000, 5, 11, device=dev), 2_000_000)

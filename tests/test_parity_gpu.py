@@ -216,6 +216,53 @@ def test_transpose_and_degree(dev):
     assert (G.row_ids().cpu().numpy() == np.repeat(np.arange(N), np.diff(G.rowptr.cpu().numpy()))).all()
 
 
+def test_symmetric_operators_are_their_own_transpose(dev, monkeypatch):
+    """CSRGraph.is_symmetric (mp_csr_is_symmetric; MP_SYM_CHECK=1 lets transpose() ask): an undirected graph — both
+    directions stored, as the reference's loaders produce (transform.py:11-38) — is recognised and transpose() returns
+    the graph itself (no sort); mirrored
+    entries with different values, a missing mirror, a repeated entry or a rectangular operator are not; the sorted
+    transpose of a symmetric operator equals the operator field for field, and the backward pass through it gives the
+    gradient of the sorted one."""
+    import graphgym_amd as ga
+    from graphgym_amd import ops, graph as G_
+    g = torch.Generator().manual_seed(8)
+    N, E = 3000, 20_000
+    half = torch.randint(0, N, (2, E), generator=g)
+    half = half[:, half[0] != half[1]]
+    half = torch.unique(torch.cat([half, half.flip(0)], 1), dim=1)          # undirected, no repeats
+    w_half = torch.rand(N, N, generator=g)
+    w_sym = ((w_half + w_half.t()) / 2)[half[0], half[1]]
+    monkeypatch.setenv("MP_SYM_CHECK", "1")
+    for w in (None, w_sym):
+        S = ga.CSRGraph.from_edge_index(half.to(dev), N, None if w is None else w.to(dev), add_self_loops=True)
+        before = dict(G_.BUILDS)
+        assert S.is_symmetric() and S.transpose() is S
+        assert G_.BUILDS.get("transpose", 0) == before.get("transpose", 0)        # no sort ran
+        T = S._transpose_sorted()
+        assert torch.equal(T.rowptr, S.rowptr) and torch.equal(T.col, S.col)
+        assert (T.val is None and S.val is None) or torch.equal(T.val, S.val)
+        Sn = S.gcn_norm("row")
+        assert Sn.symmetric and Sn.transpose() is Sn
+        x = torch.randn(N, 32, generator=g).to(dev).requires_grad_(True)
+        up = torch.randn(N, 32, generator=g).to(dev)
+        ops.spmm(Sn, x, "sum").backward(up)
+        want = ops.spmm(Sn._transpose_sorted(), up, "sum")
+        assert float((x.grad - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    # not symmetric: one value changed / one direction dropped / one entry repeated / rectangular / switched off
+    w_bad = w_sym.clone()
+    w_bad[5] += 0.25
+    assert not ga.CSRGraph.from_edge_index(half.to(dev), N, w_bad.to(dev)).is_symmetric()
+    assert not ga.CSRGraph.from_edge_index(half[:, 1:].to(dev), N).is_symmetric()
+    rep = torch.cat([half, half[:, :1]], 1)
+    assert not ga.CSRGraph.from_edge_index(rep.to(dev), N).is_symmetric()
+    A = ga.CSRGraph.from_edge_index(half[:, 1:].to(dev), N)
+    assert A.transpose() is not A and A.transpose().pos is not None
+    monkeypatch.delenv("MP_SYM_CHECK")                                       # the default: nobody asks
+    S2 = ga.CSRGraph.from_edge_index(half.to(dev), N)
+    assert not S2.is_symmetric() and S2.transpose() is not S2
+    assert S2.is_symmetric(run=True) and S2.transpose() is S2               # ... unless told to
+
+
 # --------------------------------------------------------------------------- aggregation
 def test_aggregation_matches_golden(dev, golden):
     import graphgym_amd as ga
