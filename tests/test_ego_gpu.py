@@ -141,3 +141,35 @@ def test_csr_written_by_the_expansion_equals_the_csr_built_from_its_edge_list(de
     assert len(ego_batch(base, cen, radius)) == 4
     loopy = ga.CSRGraph.from_edge_index(torch.cat([ei0, torch.tensor([[7], [7]], device=dev)], 1), n)
     assert ego_batch(loopy, cen[:5], radius, csr=loops)[4] is None
+
+
+def test_attention_backward_on_the_expansion_s_own_csr(dev):
+    """The CSR an expansion writes is flagged symmetric (transpose() is the graph itself), but attention scores and
+    coefficients are per-entry values that are NOT symmetric: their backward passes permute them through the sorted
+    transpose's entry map.  Scores, softmax and the weighted aggregation (TfgIDLayer.py:333-355), forward and all three
+    gradients, must equal those on the CSR built from the returned edge list."""
+    import graphgym_amd as ga
+    from graphgym_amd import graphgen, ops
+    from graphgym_amd.ego import ego_batch
+    n = 5000
+    base = ga.CSRGraph.from_edge_index(graphgen.ba_edge_index(n, 3, seed=4, device=dev), n)
+    cen = torch.randint(0, n, (64,), generator=torch.Generator().manual_seed(2)).to(dev)
+    ei, orig, ids, ego_of, g = ego_batch(base, cen, 2, csr="add")
+    assert g is not None and g.symmetric and g.transpose() is g
+    n2 = orig.numel()
+    want = ga.CSRGraph.from_edge_index(ei, n2, dst_row=1, add_self_loops=True)
+    assert torch.equal(g.col, want.col) and not want.symmetric
+    gen = torch.Generator().manual_seed(9)
+    q0, k0, v0 = (torch.randn(n2, 32, generator=gen).to(dev) for _ in range(3))
+    up = torch.randn(n2, 32, generator=gen).to(dev)
+    outs = []
+    for G in (g, want):
+        q, k, v = (t.clone().requires_grad_(True) for t in (q0, k0, v0))
+        for heads in (1, 4):
+            sc = ops.sddmm_dot(G, q, k, heads=heads, scale=0.25)
+            a = ops.edge_softmax(G, sc)
+            y = ops.spmm_edge_values(G, a, v, heads=heads)
+            y.backward(up)
+        outs.append((y.detach(), q.grad, k.grad, v.grad))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
