@@ -173,3 +173,37 @@ def test_attention_backward_on_the_expansion_s_own_csr(dev):
         outs.append((y.detach(), q.grad, k.grad, v.grad))
     for a_, b_ in zip(*outs):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("radius", [1, 2])
+def test_repeated_isolated_and_single_centres(dev, radius):
+    """A sampled batch may name a centre twice (two separate components, transform.py:24-36 builds one ego per listed
+    node), a centre without any edge (an ego of one node), or a single centre; each ego of a batch must be what the
+    batch of that centre alone gives, whatever else is in the batch."""
+    import graphgym_amd as ga
+    from graphgym_amd import graphgen
+    from graphgym_amd.ego import ego_batch
+    n = 3000
+    ei = graphgen.ba_edge_index(n - 2, 3, seed=6, device=dev)               # nodes n-2, n-1 have no edges
+    base = ga.CSRGraph.from_edge_index(ei, n)
+    cen = torch.tensor([5, 0, 5, n - 1, 77, 0, n - 2, 5], device=dev)       # 0: a hub; repeats; isolated nodes
+    for csr in (None, "add"):
+        out = ego_batch(base, cen, radius, csr=csr)
+        e2, orig, ids, ego_of = out[:4]
+        assert ids.tolist() == list(range(cen.numel())) and orig[:cen.numel()].tolist() == cen.tolist()
+        sizes = torch.bincount(ego_of, minlength=cen.numel())
+        for k, c in enumerate(cen.tolist()):
+            one = ego_batch(base, torch.tensor([c], device=dev), radius, csr=csr)
+            assert int(sizes[k]) == one[1].numel()
+            mem = orig[ego_of == k]
+            assert torch.equal(torch.sort(mem).values, torch.sort(one[1]).values)
+            m = ego_of[e2[0]] == k
+            got = set(zip(orig[e2[0][m]].tolist(), orig[e2[1][m]].tolist()))
+            want = set(zip(one[1][one[0][0]].tolist(), one[1][one[0][1]].tolist()))
+            assert got == want and int(m.sum()) == one[0].size(1)
+        assert int(sizes[3]) == 1 and int(sizes[6]) == 1                    # the isolated centres
+        assert torch.equal(sizes[0], sizes[2]) and torch.equal(sizes[0], sizes[7]) and torch.equal(sizes[1], sizes[5])
+        if csr is not None:
+            g = out[4]
+            want = ga.CSRGraph.from_edge_index(e2, orig.numel(), dst_row=1, add_self_loops=True)
+            assert torch.equal(g.rowptr, want.rowptr) and torch.equal(g.col, want.col)
