@@ -139,87 +139,251 @@ __global__ __launch_bounds__(kBlock) void sddmm_add_kernel(const int32_t* __rest
   }
 }
 
-// softmax over a row's entries.  Rows of a scale-free graph are short (11 entries on average at m = 5), so a row is
-// given to a group of kSmLanes = 16 lanes — four rows per wave, one trip of the loops for most rows — instead of a
-// whole wave (which left 53 of 64 lanes idle and made the kernel latency-bound: 2.9 ms at 10^7 rows against 0.15 ms
-// of traffic).  The few hub rows simply take more trips.  Reductions stay inside the aligned 16-lane group.
+// softmax over a row's entries, in three tiers decided per row inside ONE launch (round 4; no row lists, no workspace):
+//   short  (<= kSmShort = 16 entries — 90 % of the rows of a scale-free graph, 11 entries on average at m = 5): ONE lane
+//          per row, the row's scores in registers — one load and one store per entry instead of three sweeps (the three
+//          sweeps of rounds 1-3 were four dependent memory latencies per round of a workgroup: 1.86 ms at 10^7 rows
+//          against 0.15 ms of traffic); adjacent lanes hold adjacent rows, so a wave reads one contiguous stretch
+//   medium (<= kSmLong = 2048): a group of kSmLanes = 16 lanes, three sweeps, reductions inside the aligned group
+//   long   the WHOLE workgroup (256 lanes, block-wide reductions): a hub row of 20 000 entries was 1 200 trips of its 16
+//          lanes, one load in flight each
+// The lanes of a workgroup vote per round through LDS: medium and long rows are queued there and worked off by groups /
+// by everyone after the short rows.  Rows are dealt to workgroups in chunks of 16 (a hubs-first numbering does not put
+// the 256 longest rows into workgroup 0).  Which queue slot a row gets does not enter its result: same bits every run.
 constexpr int kSmLanes = 16;
+constexpr int kSmShort = 16;
+constexpr int kSmLong = 2048;
 
-__global__ __launch_bounds__(kBlock) void row_softmax_kernel(const int32_t* __restrict__ rowptr, int64_t N,
-                                                             int32_t heads, const float* s, float* out) {
-  const int sub = threadIdx.x % kSmLanes;
-  const int64_t groups = (int64_t)gridDim.x * (kBlock / kSmLanes);
-  const int64_t rounds = (N + groups - 1) / groups;     // the same for every lane: shuffles need the wave converged
+__device__ __forceinline__ float block_max_f32(float v, float* buf) {
+  for (int off = kWave >> 1; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+  if ((threadIdx.x & (kWave - 1)) == 0) buf[threadIdx.x / kWave] = v;
+  __syncthreads();
+  v = buf[0];
+#pragma unroll
+  for (int w = 1; w < kWavesPerBlock; ++w) v = fmaxf(v, buf[w]);
+  __syncthreads();
+  return v;
+}
+
+__device__ __forceinline__ float block_sum_f32(float v, float* buf) {
+  for (int off = kWave >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) buf[threadIdx.x / kWave] = v;
+  __syncthreads();
+  v = buf[0];
+#pragma unroll
+  for (int w = 1; w < kWavesPerBlock; ++w) v += buf[w];   // (wave order: the same bits every run)
+  __syncthreads();
+  return v;
+}
+
+// The row loop shared by the three kernels below.
+//   short_row(r, e0, len): one lane, 0 < len <= short_max <= kSmShort (called divergently: no shuffles, no barriers
+//                          inside); short_max = 0 sends every row to the groups
+//   medium_rows(r, e0, e1, trips, sub): this 16-lane group's queued row (e0 == e1: none this trip; `trips` is the wave's
+//                                       maximum, so the shuffles inside stay converged)
+//   long_row(r, e0, e1, buf): the whole workgroup on one row (every thread calls it; buf: kWavesPerBlock floats)
+template <class ShortRow, class MediumRows, class LongRow>
+__device__ __forceinline__ void softmax_row_loop(const int32_t* __restrict__ rowptr, int64_t N, int short_max,
+                                                 ShortRow short_row, MediumRows medium_rows, LongRow long_row) {
+  __shared__ int med_s[kBlock], med_e0_s[kBlock], med_e1_s[kBlock];   // (row, first entry, end: no second trip to rowptr)
+  __shared__ int long_s[kBlock];
+  __shared__ int n_med_s, n_long_s;
+  __shared__ float red_s[kWavesPerBlock];
+  const int sub = threadIdx.x % kSmLanes, grp = threadIdx.x / kSmLanes;
+  const int64_t per_round = (int64_t)gridDim.x * kBlock;
+  const int64_t rounds = (N + per_round - 1) / per_round;   // the same for every lane: barriers and shuffles need everyone
   for (int64_t it = 0; it < rounds; ++it) {
-    const int64_t r0 = it * groups + (int64_t)blockIdx.x * (kBlock / kSmLanes) + threadIdx.x / kSmLanes;
+    // chunks of 16 consecutive rows, dealt round-robin over the workgroups
+    const int64_t r0 = it * per_round + ((int64_t)grp * gridDim.x + blockIdx.x) * kSmLanes + sub;
     const bool live = r0 < N;
     const int64_t r = live ? r0 : N - 1;
     const int e0 = live ? rowptr[r] : 0, e1 = live ? rowptr[r + 1] : 0;
-    int trips = (e1 - e0 + kSmLanes - 1) / kSmLanes;
-    for (int off = kSmLanes; off < kWave; off <<= 1) trips = max(trips, __shfl_xor(trips, off, kWave));
-    for (int h = 0; h < heads; ++h) {
-      float m = -INFINITY;
-      for (int t = 0; t < trips; ++t) {
-        const int e = e0 + t * kSmLanes + sub;
-        if (e < e1) m = fmaxf(m, s[(int64_t)e * heads + h]);
-      }
-      for (int off = kSmLanes >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
-      float z = 0.f;
-      for (int t = 0; t < trips; ++t) {
-        const int e = e0 + t * kSmLanes + sub;
-        if (e < e1) z += expf(s[(int64_t)e * heads + h] - m);
-      }
-      z = wave_sum_seg(z, kSmLanes);
-      for (int t = 0; t < trips; ++t) {
-        const int e = e0 + t * kSmLanes + sub;
-        if (e < e1) out[(int64_t)e * heads + h] = expf(s[(int64_t)e * heads + h] - m) / z;
-      }
+    const int len = e1 - e0;
+    if (threadIdx.x == 0) { n_med_s = 0; n_long_s = 0; }
+    __syncthreads();
+    if (len > kSmLong) long_s[atomicAdd(&n_long_s, 1)] = (int)r;
+    else if (len > short_max) {
+      const int slot = atomicAdd(&n_med_s, 1);
+      med_s[slot] = (int)r; med_e0_s[slot] = e0; med_e1_s[slot] = e1;
     }
+    __syncthreads();
+    if (len > 0 && len <= short_max) short_row(r, e0, len);
+    const int n_med = n_med_s, n_long = n_long_s;           // (block-uniform)
+    for (int base = 0; base < n_med; base += kBlock / kSmLanes) {
+      const int q = base + grp;
+      const bool has = q < n_med;
+      const int rm = has ? med_s[q] : 0;
+      const int m0 = has ? med_e0_s[q] : 0, m1 = has ? med_e1_s[q] : 0;
+      int trips = (m1 - m0 + kSmLanes - 1) / kSmLanes;
+      for (int off = kSmLanes; off < kWave; off <<= 1) trips = max(trips, __shfl_xor(trips, off, kWave));
+      medium_rows((int64_t)rm, m0, m1, trips, sub);
+    }
+    for (int q = 0; q < n_long; ++q) {
+      const int rl = long_s[q];
+      long_row((int64_t)rl, rowptr[rl], rowptr[rl + 1], red_s);
+    }
+    __syncthreads();                                        // the queues are rewritten by the next round
   }
+}
+
+__global__ __launch_bounds__(kBlock) void row_softmax_kernel(const int32_t* __restrict__ rowptr, int64_t N,
+                                                             int32_t heads, const float* s, float* out) {
+  softmax_row_loop(rowptr, N, kSmShort,
+    [&](int64_t, int e0, int len) {
+      for (int h = 0; h < heads; ++h) {
+        float v[kSmShort];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kSmShort; ++j) {
+          v[j] = j < len ? s[(int64_t)(e0 + j) * heads + h] : -INFINITY;
+          m = fmaxf(m, v[j]);
+        }
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < kSmShort; ++j) {
+          v[j] = j < len ? expf(v[j] - m) : 0.f;
+          z += v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < kSmShort; ++j)
+          if (j < len) out[(int64_t)(e0 + j) * heads + h] = v[j] / z;
+      }
+    },
+    [&](int64_t, int e0, int e1, int trips, int sub) {
+      // the first kSmKeep trips (rows of up to 64 entries: 97 % of the medium rows) stay in registers — one load and one
+      // store per entry; only the rest of a longer row is swept three times
+      constexpr int kSmKeep = 4;
+      for (int h = 0; h < heads; ++h) {
+        float v[kSmKeep];
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < kSmKeep; ++t) {
+          const int e = e0 + t * kSmLanes + sub;
+          v[t] = e < e1 ? s[(int64_t)e * heads + h] : -INFINITY;
+          m = fmaxf(m, v[t]);
+        }
+        for (int t = kSmKeep; t < trips; ++t) {
+          const int e = e0 + t * kSmLanes + sub;
+          if (e < e1) m = fmaxf(m, s[(int64_t)e * heads + h]);
+        }
+        for (int off = kSmLanes >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+        float z = 0.f;
+#pragma unroll
+        for (int t = 0; t < kSmKeep; ++t) {
+          v[t] = e0 + t * kSmLanes + sub < e1 ? expf(v[t] - m) : 0.f;
+          z += v[t];
+        }
+        for (int t = kSmKeep; t < trips; ++t) {
+          const int e = e0 + t * kSmLanes + sub;
+          if (e < e1) z += expf(s[(int64_t)e * heads + h] - m);
+        }
+        z = wave_sum_seg(z, kSmLanes);
+#pragma unroll
+        for (int t = 0; t < kSmKeep; ++t) {
+          const int e = e0 + t * kSmLanes + sub;
+          if (e < e1) out[(int64_t)e * heads + h] = v[t] / z;
+        }
+        for (int t = kSmKeep; t < trips; ++t) {
+          const int e = e0 + t * kSmLanes + sub;
+          if (e < e1) out[(int64_t)e * heads + h] = expf(s[(int64_t)e * heads + h] - m) / z;
+        }
+      }
+    },
+    [&](int64_t, int e0, int e1, float* buf) {
+      for (int h = 0; h < heads; ++h) {
+        float m = -INFINITY;
+#pragma unroll 4
+        for (int e = e0 + (int)threadIdx.x; e < e1; e += kBlock) m = fmaxf(m, s[(int64_t)e * heads + h]);
+        m = block_max_f32(m, buf);
+        float z = 0.f;
+#pragma unroll 4
+        for (int e = e0 + (int)threadIdx.x; e < e1; e += kBlock) z += expf(s[(int64_t)e * heads + h] - m);
+        z = block_sum_f32(z, buf);
+#pragma unroll 4
+        for (int e = e0 + (int)threadIdx.x; e < e1; e += kBlock)
+          out[(int64_t)e * heads + h] = expf(s[(int64_t)e * heads + h] - m) / z;
+      }
+    });
 }
 
 // Additive attention coefficients in one pass, all heads: alpha[e, h] = softmax over row r of
 // leaky_relu(a_dst[r, h] + a_src[col[e], h])  (idconv.py:319-327; torch_geometric GATConv [3P]).  The scores are never
-// stored: the three sweeps of the row softmax (max, sum, write) recompute them from the two per-node terms, which sit
-// in L2.  Replaces one sddmm_add launch per head + a concatenation + the row softmax of round 1.
+// stored: short rows compute them once into registers; the sweeps of the longer rows recompute them from the two
+// per-node terms, which sit in L2.  Replaces one sddmm_add launch per head + a concatenation + the row softmax of round 1.
 __global__ __launch_bounds__(kBlock) void gat_alpha_kernel(const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col, int64_t N, int32_t heads,
                                                            const float* __restrict__ a_dst,
                                                            const float* __restrict__ a_src, float slope, float* out) {
-  const int sub = threadIdx.x % kSmLanes;
-  const int64_t groups = (int64_t)gridDim.x * (kBlock / kSmLanes);
-  const int64_t rounds = (N + groups - 1) / groups;     // the same for every lane: shuffles need the wave converged
-  for (int64_t it = 0; it < rounds; ++it) {
-    const int64_t r0 = it * groups + (int64_t)blockIdx.x * (kBlock / kSmLanes) + threadIdx.x / kSmLanes;
-    const bool live = r0 < N;
-    const int64_t r = live ? r0 : N - 1;
-    const int e0 = live ? rowptr[r] : 0, e1 = live ? rowptr[r + 1] : 0;
-    int trips = (e1 - e0 + kSmLanes - 1) / kSmLanes;
-    for (int off = kSmLanes; off < kWave; off <<= 1) trips = max(trips, __shfl_xor(trips, off, kWave));
-    for (int h = 0; h < heads; ++h) {
-      const float ad = a_dst[r * heads + h];
-      auto score = [&](int e) {
-        const float v = ad + a_src[(int64_t)col[e] * heads + h];
-        return v > 0.f ? v : slope * v;
-      };
-      float m = -INFINITY;
-      for (int t = 0; t < trips; ++t) {
-        const int e = e0 + t * kSmLanes + sub;
-        if (e < e1) m = fmaxf(m, score(e));
+  softmax_row_loop(rowptr, N, kSmShort,
+    [&](int64_t r, int e0, int len) {
+      int c[kSmShort];
+#pragma unroll
+      for (int j = 0; j < kSmShort; ++j) c[j] = j < len ? col[e0 + j] : 0;
+      for (int h = 0; h < heads; ++h) {
+        const float ad = a_dst[r * heads + h];
+        float v[kSmShort];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kSmShort; ++j) {
+          const float t = ad + a_src[(int64_t)c[j] * heads + h];
+          v[j] = j < len ? (t > 0.f ? t : slope * t) : -INFINITY;
+          m = fmaxf(m, v[j]);
+        }
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < kSmShort; ++j) {
+          v[j] = j < len ? expf(v[j] - m) : 0.f;
+          z += v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < kSmShort; ++j)
+          if (j < len) out[(int64_t)(e0 + j) * heads + h] = v[j] / z;
       }
-      for (int off = kSmLanes >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
-      float z = 0.f;
-      for (int t = 0; t < trips; ++t) {
-        const int e = e0 + t * kSmLanes + sub;
-        if (e < e1) z += expf(score(e) - m);
+    },
+    [&](int64_t r, int e0, int e1, int trips, int sub) {
+      for (int h = 0; h < heads; ++h) {
+        const float ad = a_dst[r * heads + h];
+        auto score = [&](int e) {
+          const float v = ad + a_src[(int64_t)col[e] * heads + h];
+          return v > 0.f ? v : slope * v;
+        };
+        float m = -INFINITY;
+        for (int t = 0; t < trips; ++t) {
+          const int e = e0 + t * kSmLanes + sub;
+          if (e < e1) m = fmaxf(m, score(e));
+        }
+        for (int off = kSmLanes >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+        float z = 0.f;
+        for (int t = 0; t < trips; ++t) {
+          const int e = e0 + t * kSmLanes + sub;
+          if (e < e1) z += expf(score(e) - m);
+        }
+        z = wave_sum_seg(z, kSmLanes);
+        for (int t = 0; t < trips; ++t) {
+          const int e = e0 + t * kSmLanes + sub;
+          if (e < e1) out[(int64_t)e * heads + h] = expf(score(e) - m) / z;
+        }
       }
-      z = wave_sum_seg(z, kSmLanes);
-      for (int t = 0; t < trips; ++t) {
-        const int e = e0 + t * kSmLanes + sub;
-        if (e < e1) out[(int64_t)e * heads + h] = expf(score(e) - m) / z;
+    },
+    [&](int64_t r, int e0, int e1, float* buf) {
+      for (int h = 0; h < heads; ++h) {
+        const float ad = a_dst[r * heads + h];
+        auto score = [&](int e) {
+          const float v = ad + a_src[(int64_t)col[e] * heads + h];
+          return v > 0.f ? v : slope * v;
+        };
+        float m = -INFINITY;
+#pragma unroll 4
+        for (int e = e0 + (int)threadIdx.x; e < e1; e += kBlock) m = fmaxf(m, score(e));
+        m = block_max_f32(m, buf);
+        float z = 0.f;
+#pragma unroll 4
+        for (int e = e0 + (int)threadIdx.x; e < e1; e += kBlock) z += expf(score(e) - m);
+        z = block_sum_f32(z, buf);
+#pragma unroll 4
+        for (int e = e0 + (int)threadIdx.x; e < e1; e += kBlock) out[(int64_t)e * heads + h] = expf(score(e) - m) / z;
       }
-    }
-  }
+    });
 }
 
 // ds = p * (dp - sum_row(p * dp))
@@ -227,32 +391,55 @@ __global__ __launch_bounds__(kBlock) void row_softmax_bwd_kernel(const int32_t* 
                                                                  int64_t N, int32_t heads,
                                                                  const float* __restrict__ p,
                                                                  const float* __restrict__ dp, float* ds) {
-  const int sub = threadIdx.x % kSmLanes;
-  const int64_t groups = (int64_t)gridDim.x * (kBlock / kSmLanes);
-  const int64_t rounds = (N + groups - 1) / groups;
-  for (int64_t it = 0; it < rounds; ++it) {
-    const int64_t r0 = it * groups + (int64_t)blockIdx.x * (kBlock / kSmLanes) + threadIdx.x / kSmLanes;
-    const bool live = r0 < N;
-    const int64_t r = live ? r0 : N - 1;
-    const int e0 = live ? rowptr[r] : 0, e1 = live ? rowptr[r + 1] : 0;
-    int trips = (e1 - e0 + kSmLanes - 1) / kSmLanes;
-    for (int off = kSmLanes; off < kWave; off <<= 1) trips = max(trips, __shfl_xor(trips, off, kWave));
-    for (int h = 0; h < heads; ++h) {
-      float t = 0.f;
-      for (int k = 0; k < trips; ++k) {
-        const int e = e0 + k * kSmLanes + sub;
-        if (e < e1) t = fmaf(p[(int64_t)e * heads + h], dp[(int64_t)e * heads + h], t);
+  // (several heads: a lane per row walks its entries once per head with a stride of `heads` — 5.3 against 4.5 ms at four
+  // heads; the groups take every row there)
+  softmax_row_loop(rowptr, N, heads == 1 ? kSmShort : 0,
+    [&](int64_t, int e0, int len) {
+      for (int h = 0; h < heads; ++h) {
+        float pv[kSmShort], dv[kSmShort];
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < kSmShort; ++j) {
+          pv[j] = j < len ? p[(int64_t)(e0 + j) * heads + h] : 0.f;
+          dv[j] = j < len ? dp[(int64_t)(e0 + j) * heads + h] : 0.f;
+          t = fmaf(pv[j], dv[j], t);
+        }
+#pragma unroll
+        for (int j = 0; j < kSmShort; ++j)
+          if (j < len) ds[(int64_t)(e0 + j) * heads + h] = pv[j] * (dv[j] - t);
       }
-      t = wave_sum_seg(t, kSmLanes);
-      for (int k = 0; k < trips; ++k) {
-        const int e = e0 + k * kSmLanes + sub;
-        if (e < e1) {
+    },
+    [&](int64_t, int e0, int e1, int trips, int sub) {
+      for (int h = 0; h < heads; ++h) {
+        float t = 0.f;
+        for (int k = 0; k < trips; ++k) {
+          const int e = e0 + k * kSmLanes + sub;
+          if (e < e1) t = fmaf(p[(int64_t)e * heads + h], dp[(int64_t)e * heads + h], t);
+        }
+        t = wave_sum_seg(t, kSmLanes);
+        for (int k = 0; k < trips; ++k) {
+          const int e = e0 + k * kSmLanes + sub;
+          if (e < e1) {
+            const int64_t i = (int64_t)e * heads + h;
+            ds[i] = p[i] * (dp[i] - t);
+          }
+        }
+      }
+    },
+    [&](int64_t, int e0, int e1, float* buf) {
+      for (int h = 0; h < heads; ++h) {
+        float t = 0.f;
+#pragma unroll 4
+        for (int e = e0 + (int)threadIdx.x; e < e1; e += kBlock)
+          t = fmaf(p[(int64_t)e * heads + h], dp[(int64_t)e * heads + h], t);
+        t = block_sum_f32(t, buf);
+#pragma unroll 4
+        for (int e = e0 + (int)threadIdx.x; e < e1; e += kBlock) {
           const int64_t i = (int64_t)e * heads + h;
           ds[i] = p[i] * (dp[i] - t);
         }
       }
-    }
-  }
+    });
 }
 
 // Y[r, c] = sum_e a[e*H + c/dh] * V[col[e], c]
@@ -356,7 +543,7 @@ int mp_csr_row_softmax_f32(const int32_t* rowptr, int64_t N, int32_t heads, cons
   if (!rowptr || N < 0 || heads <= 0) return MP_ERR_INVALID_ARG;
   if (N == 0) return MP_OK;
   if (!s || !out) return MP_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(row_softmax_kernel, dim3(flat_grid(N * kSmLanes)), dim3(kBlock), 0, as_stream(stream), rowptr, N,
+  hipLaunchKernelGGL(row_softmax_kernel, dim3(flat_grid(N)), dim3(kBlock), 0, as_stream(stream), rowptr, N,
                      heads, s, out);
   MP_LAUNCH_CHECK();
   return MP_OK;
@@ -367,7 +554,7 @@ int mp_gat_alpha_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64
   if (!rowptr || N < 0 || nnz < 0 || heads < 1 || (nnz > 0 && (!col || !a_dst || !a_src || !alpha)))
     return MP_ERR_INVALID_ARG;
   if (N == 0 || nnz == 0) return MP_OK;
-  hipLaunchKernelGGL(gat_alpha_kernel, dim3(flat_grid(N * kSmLanes)), dim3(kBlock), 0, as_stream(stream), rowptr, col,
+  hipLaunchKernelGGL(gat_alpha_kernel, dim3(flat_grid(N)), dim3(kBlock), 0, as_stream(stream), rowptr, col,
                      N, heads, a_dst, a_src, slope, alpha);
   MP_LAUNCH_CHECK();
   return MP_OK;
@@ -378,7 +565,7 @@ int mp_csr_row_softmax_bwd_f32(const int32_t* rowptr, int64_t N, int32_t heads, 
   if (!rowptr || N < 0 || heads <= 0) return MP_ERR_INVALID_ARG;
   if (N == 0) return MP_OK;
   if (!p || !dp || !ds) return MP_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3(flat_grid(N * kSmLanes)), dim3(kBlock), 0, as_stream(stream), rowptr, N,
+  hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3(flat_grid(N)), dim3(kBlock), 0, as_stream(stream), rowptr, N,
                      heads, p, dp, ds);
   MP_LAUNCH_CHECK();
   return MP_OK;

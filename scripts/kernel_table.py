@@ -89,7 +89,7 @@ t = timeit(lambda: ops._raw_sddmm_dot(g, x, x, 1, 1.0))
 rec("sddmm_stream (dot-product scores, 1 head)", t, (nnz * (d * 4 + 12) + n * d * 4) / 1e9, note="K[col] row per entry, Q[row] once per row")
 sc = ops._raw_sddmm_dot(g, x, x, 1, 1.0 / 16)
 t = timeit(lambda: ops.edge_softmax(g, sc))
-rec("row_softmax (per destination row)", t, (nnz * 8 + n * 4) / 1e9, note="16 lanes per row, 3 passes over the row's scores (L2-resident)")
+rec("row_softmax (per destination row)", t, (nnz * 8 + n * 4) / 1e9, note="a lane per short row (scores in registers), 16 lanes per medium row, the workgroup per hub row")
 del sc
 # dense transform kernels
 W = torch.randn(d, d, device=dev) * 0.05

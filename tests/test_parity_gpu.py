@@ -802,6 +802,46 @@ def test_multi_head_aggregation_in_one_launch(dev, heads, d):
     close(Vd.grad, (r64[2], r32[2]), what="dV")
 
 
+@pytest.mark.parametrize("heads", [1, 3])
+def test_row_softmax_with_hub_rows(dev, heads):
+    """mp_csr_row_softmax_f32 / _bwd_f32 with rows far beyond the 16-lane groups' reach (40 000, 3 000 and 2 049 entries
+    among short and empty rows): those rows are taken by the whole workgroup (attn.hip: softmax_row_loop).  Forward and
+    backward against the oracle's softmax (TfgIDLayer.py:333-355 through tf_sparse segment softmax), every row summing
+    to one, reproducible bit for bit."""
+    import graphgym_amd as ga
+    from graphgym_amd import ops
+    g = torch.Generator().manual_seed(60 + heads)
+    N = 40_000
+    dst = torch.cat([torch.randint(0, N, (150_000,), generator=g), torch.full((40_000,), 7), torch.full((3_000,), N - 1),
+                     torch.full((2_049,), 20_000)])
+    dst = dst[(dst % 11) != 3]                                           # empty rows
+    src = torch.randint(0, N, (dst.numel(),), generator=g)
+    G = ga.CSRGraph.from_edge_index(torch.stack([dst, src]).to(dev), N, dst_row=0)
+    rows = G.row_ids().cpu().long()
+    assert int(torch.bincount(rows, minlength=N).max()) >= 40_000
+    s = torch.randn(G.nnz, heads, generator=g) * 3
+    up = torch.randn(G.nnz, heads, generator=g)
+    sg = s.to(dev).requires_grad_(True)
+    p = ops.edge_softmax(G, sg)
+    p.backward(up.to(dev))
+
+    def ref(c):
+        sr = c(s).clone().requires_grad_(True)
+        pr = R.softmax(sr, rows, N)
+        pr.backward(c(up))
+        return pr.detach(), sr.grad
+    r64, r32 = both(ref)
+    close(p, (r64[0], r32[0]), what="softmax with hub rows")
+    al, dl = r64[0], up.double()
+    rowdot = torch.zeros(N, heads, dtype=torch.float64).index_add_(0, rows, (al * dl).abs())
+    close(sg.grad, (r64[1], r32[1]), what="softmax backward with hub rows", mag=al.abs() * (dl.abs() + rowdot[rows]))
+    sums = torch.zeros(N, heads, dtype=torch.float64).index_add_(0, rows, p.detach().cpu().double())
+    has = torch.bincount(rows, minlength=N) > 0
+    assert float((sums[has] - 1.0).abs().max()) <= 1e-5
+    p2 = ops.edge_softmax(G, sg.detach())
+    assert torch.equal(p.detach(), p2)
+
+
 @pytest.mark.parametrize("heads", [1, 4])
 def test_additive_attention_coefficients_in_one_pass(dev, heads):
     """alpha = softmax_row(leaky_relu(a_dst[row] + a_src[col])) for all heads in one launch (mp_gat_alpha_f32), forward
