@@ -1379,8 +1379,11 @@ static int launch_fused(const FusedArgs& a, hipStream_t st) {
       if (a.dout > 256) return launch_fused_pc<W, KH, 1, PF, 64, 4, 8>(a, st);   // one column block per consumer wave
       return launch_fused_pc<W, KH, 1, PF, 64, 4, 4, true>(a, st);
     } else {
-      // F = 512: the accumulators of both column blocks live across the K halves (8 consumers with one block each
-      // need 12 waves of <= 168 registers and spill); the two blocks walk K together instead
+      // F = 512 -> 512: the accumulators live across the K halves.  Eight multiplying waves with one 64-column block each
+      // (152 registers; 168 + 20 B of scratch with the self term) against four with two blocks walking K together
+      // (rounds 2-3: the one-block form spilled then): 50.8 vs 51.6 ms, with the self term 52.1 vs 52.7 — round 4, same
+      // process and buffers, same bits (MP_FUSED_VARIANT=7: the four-wave form)
+      if (a.dout == 512 && v != 7) return launch_fused_pc<W, KH, 1, PF, 64, 4, 8, true>(a, st);
       if (a.dout == 512) return launch_fused_pc<W, KH, 2, PF, 64, 4, 4, true>(a, st);
       if (a.dout > 256) return launch_fused_tiles<W, KH, NCB, PF>(a, st);   // (a ragged second block: the one-role kernel)
       return launch_fused_pc<W, KH, 1, PF, 64, 4, 4, true>(a, st);
