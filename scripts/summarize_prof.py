@@ -40,7 +40,8 @@ def is_agg(name):
         return True
     if "agg_dense_pc_kernel<" in name:
         args = name.split("agg_dense_pc_kernel<", 1)[1].split(">", 1)[0].split(",")
-        return args[-1].strip() == "true"
+        # <W, WEIGHTED, U, KH, NCB, PF, NT_OUT, BF16X3, TR, NP, NC, HAS_S, AGG_ONLY[, MAXR]>: the sum / mean aggregation
+        return len(args) > 12 and args[12].strip() == "true" and (len(args) < 14 or args[13].strip() == "false")
     return False
 
 
