@@ -20,6 +20,7 @@ and beside them the build alone (`batch_build_ms`), the exposed wait for the exc
 (`graph_builds_inside_steps`: 0 when the pipeline prepared everything).  All timed loops run under
 pipeline.quiet_gc(): Python's cycle collector is kept to its young generation (a full collection is 40-80 ms).
 """
+import os
 import time
 
 import numpy as np
@@ -41,8 +42,9 @@ def run(args, rank, world, dev):
 
     import graphgym_amd as ga
     from graphgym_amd import dist as D, graph as G, graphgen, harness as H, placement
-    from graphgym_amd.pipeline import EgoBatchPipeline, quiet_gc
+    from graphgym_amd.pipeline import EgoBatchPipeline, quiet_gc, fit_allocator_to_changing_shapes
 
+    alloc_conf = fit_allocator_to_changing_shapes()
     kind = getattr(args, "step_model", "idgcn")
     n0 = min(args.nodes, getattr(args, "step_nodes", 2_000_000))
     f_in, d = (128, 128) if kind == "idgcn" else (512, 512)
@@ -139,14 +141,20 @@ def run(args, rank, world, dev):
     del b0
 
     # ---- (2) a fresh batch per step ------------------------------------------------------------------------------------
-    def fresh(steps, overlap, first_k):
-        p = EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev, threaded=overlap, csr=csr)
+    def fresh(steps, overlap, first_k, pipe=None):
+        p = pipe if pipe is not None else \
+            EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev, threaded=overlap, csr=csr)
         if not overlap:
             p.side = torch.cuda.current_stream(dev)
         nnz, nodes, builds_in_steps, imb = 0, 0, 0, []
         host = 0.0
-        c, y, _ = sample(first_k)
-        p.submit(c, y)
+        # builds are started TWO steps ahead (MP_PIPE_DEPTH): a build then has two step times to finish in, and a driver
+        # allocation it triggers (new shapes every batch) no longer lands in front of the step that needs the batch —
+        # ID-GCN 16.9 -> 16.4 ms per step, ID-GIN at 4 096 centres 207.9 -> 157.9 (replayed: 151.1); three ahead: the same
+        ahead = max(1, int(os.environ.get("MP_PIPE_DEPTH", "2"))) if overlap else 1
+        for j in range(ahead):
+            c, y, _ = sample(first_k + j)
+            p.submit(c, y)
         D.barrier()
         torch.cuda.synchronize()
         with quiet_gc() as tick:
@@ -161,8 +169,8 @@ def run(args, rank, world, dev):
                 p.done()
                 nnz += b.edges + (b.nodes if self_loops else 0)
                 nodes += b.nodes
-                if k + 1 < steps:
-                    c, y, im = sample(first_k + k + 1)
+                if k + ahead < steps:
+                    c, y, im = sample(first_k + k + ahead)
                     imb.append(im)
                     p.submit(c, y)
                 del b
@@ -170,19 +178,26 @@ def run(args, rank, world, dev):
             torch.cuda.synchronize()
             D.barrier()
             dt_loop = time.perf_counter() - t_start
-        p.close()
+        if pipe is None:
+            p.close()
         return dt_loop, nnz, nodes, builds_in_steps, imb, host / steps
 
     # new shapes every step: the allocator settles, and placement spends its per-process probe budget (placement.py:
     # MP_PLACE_BUDGET_MS) — the warm-up runs until it is spent, the timed loop is the steady state
+    # ONE pipeline for the warm-up and the timed loop, as a training run keeps one for its life: the warm-up batches fill
+    # the pool of its stream, the timed loop is the steady state (no driver allocation: `driver_allocs_in_fresh_steps`)
+    p_run = EgoBatchPipeline(base, x_base, radius, prepare=prepare, device=dev, threaded=True, csr=csr)
     for rep in range(4):
         spent = placement.stats(dev)["probe_ms_total"]
-        fresh(warm, True, 10_000 + 100 * rep)
+        fresh(warm, True, 10_000 + 100 * rep, pipe=p_run)
         if placement.stats(dev)["probe_ms_total"] == spent:
             break
     place_before = placement.stats(dev)
-    dt_fresh, nnz_fresh, nodes_fresh, builds_fresh, imbs, host_enq = fresh(args.steps, True, 20_000)
+    mem_before = torch.cuda.memory_stats(dev)
+    dt_fresh, nnz_fresh, nodes_fresh, builds_fresh, imbs, host_enq = fresh(args.steps, True, 20_000, pipe=p_run)
     place_after = placement.stats(dev)
+    mem_after = torch.cuda.memory_stats(dev)
+    p_run.close()
     dt_fresh = D.all_reduce_max(dt_fresh, dev)
     dt_serial, _, _, _, _, _ = fresh(args.steps, False, 20_000)
     dt_serial = D.all_reduce_max(dt_serial, dev)
@@ -232,6 +247,12 @@ def run(args, rank, world, dev):
             "host_enqueue_ms_per_fresh_step": host_enq * 1e3,
             "graph_builds_inside_steps": int(builds_fresh),
             "placement_probes_in_fresh_steps": place_after["probed_pairs"] - place_before["probed_pairs"],
+            # driver allocations / frees inside the timed fresh-batch loop (each one stalls the device: hipMalloc / hipFree
+            # are synchronous; new batch shapes every step make the caching allocator ask for them until its pools fit)
+            "driver_allocs_in_fresh_steps": int(mem_after.get("num_device_alloc", 0) - mem_before.get("num_device_alloc", 0)),
+            "driver_frees_in_fresh_steps": int(mem_after.get("num_device_free", 0) - mem_before.get("num_device_free", 0)),
+            "reserved_gb_after_fresh_steps": round(mem_after.get("reserved_bytes.all.current", 0) / 1e9, 2),
+            "allocator_settings": alloc_conf,
             "ms_per_step_no_exchange": dt_local / args.steps * 1e3,
             "allreduce_exposed_ms": exposed, "allreduce_ms": t_ar * 1e3,
             "allreduce_bytes": 4 * n_par, "allreduce_buckets": len(bucket.buckets),

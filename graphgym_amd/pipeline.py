@@ -9,6 +9,8 @@ enqueues without building or synchronising anything itself.
 
 The loop:   pipe.submit(c0, y0)
             for k: b = pipe.get(); step(b); pipe.done(); pipe.submit(c[k+1], y[k+1])
+(a caller may run further ahead — submit d batches before the loop, then one per step: batches are handed out in the
+order they were submitted, and a build then has d steps to finish in)
 (the step is enqueued FIRST, then the next build is started: the host blocks only in the build's size reads, on the side
 stream, while the main stream works through the step it already holds).
 
@@ -20,6 +22,7 @@ behind step k - 1 (`done()`; the event BEFORE the last one — waiting for step 
 and only then are the batches up to k - 1 released; batch k stays alive until build k + 2 starts, whatever the caller does
 with its own reference.  The main stream waits for a batch's `built` event before its first launch.  Centres and labels arrive as HOST tensors and are uploaded on the side stream (an upload on the main
 stream would sit behind the queued step).  No record_stream bookkeeping, no device-wide synchronisation."""
+import collections
 import contextlib
 import gc
 import os
@@ -52,10 +55,15 @@ class EgoBatchPipeline:
         # behind the step's long HBM-bound launches every one of those reads waits for a slot (build 7.5 ms alone, ~18 ms
         # beside a step), at high priority its launches take the next free compute units
         lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        # The stream is this pipeline's own and lives as long as it does: keep ONE pipeline open for a whole run (the
+        # caching allocator keeps a pool per stream: the first batches of a new stream go to the driver for their memory,
+        # later ones find it cached — bench_step warms and times the same pipeline).  One process-wide stream for every
+        # pipeline was measured and lost the overlap (20.1 against 16.3 ms per ID-GCN step when the stream had been created
+        # before the process group's first collective; cause not established) — not done.
         self.side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MP_PIPE_PRIORITY", hi)))
         self._done = [None, None]          # events behind the last two steps on the main stream
         self._held = []                    # the batches handed out last: the pipeline keeps them alive until it is safe
-        self._pending = None
+        self._pending = collections.deque()  # submitted, not yet handed out (more than one: the caller runs ahead by `depth`)
         self._first = True
         self._pool = None
         # a batch's buffers live for one step: no (read, output) pair of the aggregation launches is ever seen twice, so
@@ -83,10 +91,11 @@ class EgoBatchPipeline:
         # handed to the build and overwritten under the running step — a GPU memory fault, found the hard way).
         del self._held[:-1]
         if self._pool is not None and self.side != main:
-            self._pending = self._pool.submit(self._build, centres, labels)
+            job = self._pool.submit(self._build, centres, labels)
         else:
-            self._pending = self._build(centres, labels)
-        return self._pending
+            job = self._build(centres, labels)
+        self._pending.append(job)
+        return job
 
     def _build(self, centres, labels):
         torch.cuda.set_device(self.device)
@@ -127,8 +136,8 @@ class EgoBatchPipeline:
                         nodes=int(orig.numel()), edges=int(ei.size(1)), ego_stats=dict(_ego.last_stats), timing=timing)
 
     def get(self):
-        """the submitted batch, usable on the current (main) stream"""
-        b, self._pending = self._pending, None
+        """the oldest submitted batch, usable on the current (main) stream"""
+        b = self._pending.popleft()
         if hasattr(b, "result"):
             b = b.result()                                 # (re-raises what the worker raised)
         torch.cuda.current_stream(self.device).wait_event(b.built)
@@ -136,6 +145,11 @@ class EgoBatchPipeline:
         return b
 
     def close(self):
+        for job in self._pending:                          # builds nobody asked for: let them finish before the streams go
+            if hasattr(job, "result"):
+                job.result()
+        self._pending.clear()
+        self.side.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
         self._held.clear()
         if self._paused:
@@ -151,6 +165,23 @@ class EgoBatchPipeline:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self._done = [self._done[1], ev]
+
+
+def fit_allocator_to_changing_shapes(divisions=8):
+    """Every fresh batch has its own sizes, and torch's caching allocator hands a cached block only to a request it
+    covers: with exact sizes the pools keep missing and the allocator keeps going to the driver (hipMalloc is synchronous
+    and stalls the device: ~1 per step after 100 batches, 53 GB reserved for a 6 GB working set — bench_step's
+    `driver_allocs_in_fresh_steps`).  Rounding large requests up to 1/`divisions` steps between powers of two
+    (`roundup_power2_divisions`) makes batches of similar size share blocks.  Returns what was set (None: the allocator
+    does not take settings at run time)."""
+    conf = f"roundup_power2_divisions:{int(divisions)}"
+    if os.environ.get("MP_KEEP_ALLOCATOR") == "1":
+        return None
+    try:
+        torch.cuda.memory._set_allocator_settings(conf)
+        return conf
+    except Exception:                                      # (an allocator backend without run-time settings)
+        return None
 
 
 def builds_snapshot():
