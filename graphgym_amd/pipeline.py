@@ -177,11 +177,16 @@ def fit_allocator_to_changing_shapes(divisions=8):
     conf = f"roundup_power2_divisions:{int(divisions)}"
     if os.environ.get("MP_KEEP_ALLOCATOR") == "1":
         return None
-    try:
-        torch.cuda.memory._set_allocator_settings(conf)
-        return conf
-    except Exception:                                      # (an allocator backend without run-time settings)
-        return None
+    for setter in (getattr(torch._C, "_accelerator_setAllocatorSettings", None),
+                   getattr(torch.cuda.memory, "_set_allocator_settings", None)):
+        if setter is None:
+            continue
+        try:
+            setter(conf)
+            return conf
+        except Exception:                                  # (an allocator backend without run-time settings)
+            continue
+    return None
 
 
 def builds_snapshot():

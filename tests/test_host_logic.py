@@ -318,3 +318,12 @@ def test_quiet_gc_disables_automatic_collection_and_restores_it():
         for _ in range(20):
             tick()
     assert gc.isenabled()
+
+
+def test_allocator_settings_for_changing_batch_shapes(monkeypatch):
+    """pipeline.fit_allocator_to_changing_shapes: sets torch's roundup_power2_divisions at run time (what a loop with new
+    batch shapes every step needs, bench_step's driver_allocs_in_fresh_steps) and can be switched off"""
+    from graphgym_amd.pipeline import fit_allocator_to_changing_shapes
+    assert fit_allocator_to_changing_shapes(8) in ("roundup_power2_divisions:8", None)
+    monkeypatch.setenv("MP_KEEP_ALLOCATOR", "1")
+    assert fit_allocator_to_changing_shapes(8) is None
