@@ -84,20 +84,22 @@ __global__ __launch_bounds__(kBlock) void coo_keys_kernel(const int64_t* __restr
   }
 }
 
-// rowptr[r] = first sorted position whose key >= r << shift, r = 0..N
-__global__ __launch_bounds__(kBlock) void rowptr_from_keys_kernel(const uint64_t* __restrict__ keys,
-                                                                  int64_t M, int64_t N, int shift,
-                                                                  int32_t* rowptr) {
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= N;
-       r += (int64_t)gridDim.x * blockDim.x) {
-    const uint64_t target = (uint64_t)r << shift;
-    int64_t lo = 0, hi = M;
-    while (lo < hi) {
-      const int64_t mid = lo + ((hi - lo) >> 1);
-      if (keys[mid] >= target) hi = mid; else lo = mid + 1;
-    }
-    rowptr[r] = (int32_t)lo;
+// Row starts from the sorted keys, written by the threads that walk the keys anyway (round 4; rounds 1-3 ran a
+// separate launch with one binary search over all keys per row): position k opens every row in (row(k-1), row(k)] — its
+// own and the empty rows in front of it — and the last position closes the rows behind it; rows are capped at N (the
+// "removed" marker of the COO build), so rowptr[N] = the count of kept entries.
+__device__ __forceinline__ void row_starts_from_keys(const uint64_t* __restrict__ keys, int64_t k, int64_t M, int64_t N,
+                                                      int shift, uint64_t key, int32_t* __restrict__ rowptr) {
+  int64_t row = (int64_t)(key >> shift);
+  if (row > N) row = N;
+  int64_t prev = -1;
+  if (k > 0) {
+    prev = (int64_t)(keys[k - 1] >> shift);
+    if (prev > N) prev = N;
   }
+  for (int64_t r = prev + 1; r <= row; ++r) rowptr[r] = (int32_t)k;
+  if (k == M - 1)
+    for (int64_t r = row + 1; r <= N; ++r) rowptr[r] = (int32_t)M;
 }
 
 __global__ __launch_bounds__(kBlock) void coo_emit_kernel(const uint64_t* __restrict__ keys,
@@ -105,11 +107,12 @@ __global__ __launch_bounds__(kBlock) void coo_emit_kernel(const uint64_t* __rest
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ loop_w,
                                                           int64_t M, int64_t E, int64_t N, float fill,
-                                                          int keep, int shift, int32_t* col, float* val,
-                                                          int32_t* eid) {
+                                                          int keep, int shift, int32_t* rowptr, int32_t* col,
+                                                          float* val, int32_t* eid) {
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < M;
        k += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t key = keys[k];
+    row_starts_from_keys(keys, k, M, N, shift, key, rowptr);
     if ((int64_t)(key >> shift) >= N) continue;  // removed entry
     const uint32_t p = pay[k];
     col[k] = (int32_t)(uint32_t)(key & (((uint64_t)1 << shift) - 1));
@@ -230,11 +233,12 @@ __global__ __launch_bounds__(kBlock) void csr_symmetric_kernel(const int32_t* __
 __global__ __launch_bounds__(kBlock) void transpose_emit_kernel(const uint64_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ pay,
                                                                 const float* __restrict__ val,
-                                                                int64_t nnz, int32_t* t_col, float* t_val,
-                                                                int32_t* pos) {
+                                                                int64_t nnz, int64_t N, int32_t* t_rowptr, int32_t* t_col,
+                                                                float* t_val, int32_t* pos) {
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz;
        k += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t p = pay[k];
+    row_starts_from_keys(keys, k, nnz, N, 32, keys[k], t_rowptr);
     t_col[k] = (int32_t)(uint32_t)keys[k];
     if (t_val && val) t_val[k] = val[p];
     if (pos) pos[k] = (int32_t)p;
@@ -245,6 +249,7 @@ __global__ __launch_bounds__(kBlock) void transpose_emit_kernel(const uint64_t* 
 // 10^4-entry hub row is split over the group instead of serialising one thread.
 constexpr int kRowLanes = 16;
 
+template <bool INV_SQRT = false>   // INV_SQRT: deg[r] = 1 / sqrt(row sum), 0 where that is not finite (inv_sqrt_kernel's rule)
 __global__ __launch_bounds__(kBlock) void degree_row_kernel(const int32_t* __restrict__ rowptr,
                                                             const float* __restrict__ val, int64_t N,
                                                             float* deg) {
@@ -265,6 +270,11 @@ __global__ __launch_bounds__(kBlock) void degree_row_kernel(const int32_t* __res
       for (int off = kRowLanes >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kRowLanes);
     } else {
       acc = (float)(e - s);
+    }
+    if constexpr (INV_SQRT) {
+      float y = 1.0f / sqrtf(acc);
+      if (isinf(y) || isnan(y)) y = 0.f;
+      acc = y;
     }
     if (sub == 0) deg[r] = acc;
   }
@@ -420,11 +430,8 @@ int mp_csr_from_coo(const int64_t* dst, const int64_t* src, const float* w, int6
   rocprim::double_buffer<uint32_t> dv(L.pay_a, L.pay_b);
   size_t cub_bytes = L.cub_bytes;
   MP_HIP(rocprim::radix_sort_pairs(L.cub, cub_bytes, dk, dv, (size_t)M, 0u, (unsigned)(shift + id_bits(N)), st));
-  hipLaunchKernelGGL(rowptr_from_keys_kernel, dim3(flat_grid(N + 1)), dim3(kBlock), 0, st, dk.current(),
-                     M, N, shift, rowptr);
-  MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(coo_emit_kernel, dim3(flat_grid(M)), dim3(kBlock), 0, st, dk.current(), dv.current(),
-                     w, L.loop_w, M, E, N, fill, keep ? 1 : 0, shift, col, val, eid);
+                     w, L.loop_w, M, E, N, fill, keep ? 1 : 0, shift, rowptr, col, val, eid);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -497,11 +504,8 @@ int mp_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val
   // the entries arrive in (row, column) order and the sort is stable: sorting on the column bits alone leaves the rows of
   // a column ascending — 20 bits at 6e5 columns (three passes) instead of 52 (seven)
   MP_HIP(rocprim::radix_sort_pairs(L.cub, cub_bytes, dk, dv, (size_t)nnz, 32u, (unsigned)(32 + id_bits(N)), st));
-  hipLaunchKernelGGL(rowptr_from_keys_kernel, dim3(flat_grid(N + 1)), dim3(kBlock), 0, st, dk.current(),
-                     nnz, N, 32, t_rowptr);
-  MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(transpose_emit_kernel, dim3(flat_grid(nnz)), dim3(kBlock), 0, st, dk.current(),
-                     dv.current(), val, nnz, t_col, t_val, pos);
+                     dv.current(), val, nnz, N, t_rowptr, t_col, t_val, pos);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -512,7 +516,7 @@ int mp_csr_degree(const int32_t* rowptr, const int32_t* col, const float* val, i
   if (N == 0) return MP_OK;
   hipStream_t st = as_stream(stream);
   if (axis == MP_AXIS_ROW) {
-    hipLaunchKernelGGL(degree_row_kernel, dim3(flat_grid(N * kRowLanes)), dim3(kBlock), 0, st, rowptr, val, N, deg);
+    hipLaunchKernelGGL(degree_row_kernel<false>, dim3(flat_grid(N * kRowLanes)), dim3(kBlock), 0, st, rowptr, val, N, deg);
     MP_LAUNCH_CHECK();
   } else if (axis == MP_AXIS_COL) {
     if (nnz > 0 && !col) return MP_ERR_INVALID_ARG;
@@ -532,10 +536,15 @@ int mp_gcn_norm_edges(const int32_t* rowptr, const int32_t* col, const float* va
   if (!rowptr || !dinv_out || N < 0 || nnz < 0 || (nnz > 0 && (!col || !val_out))) return MP_ERR_INVALID_ARG;
   if (N == 0) return MP_OK;
   hipStream_t st = as_stream(stream);
-  int rc = mp_csr_degree(rowptr, col, val, N, nnz, deg_axis, dinv_out, stream);
-  if (rc != MP_OK) return rc;
-  hipLaunchKernelGGL(inv_sqrt_kernel, dim3(flat_grid(N)), dim3(kBlock), 0, st, dinv_out, N);
-  MP_LAUNCH_CHECK();
+  if (deg_axis == MP_AXIS_ROW) {   // row sums and their inverse square roots in one launch (the same operations: same bits)
+    hipLaunchKernelGGL(degree_row_kernel<true>, dim3(flat_grid(N * kRowLanes)), dim3(kBlock), 0, st, rowptr, val, N, dinv_out);
+    MP_LAUNCH_CHECK();
+  } else {
+    int rc = mp_csr_degree(rowptr, col, val, N, nnz, deg_axis, dinv_out, stream);
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(inv_sqrt_kernel, dim3(flat_grid(N)), dim3(kBlock), 0, st, dinv_out, N);
+    MP_LAUNCH_CHECK();
+  }
   if (nnz > 0) {
     hipLaunchKernelGGL(norm_edges_kernel, dim3(flat_grid(N * kRowLanes)), dim3(kBlock), 0, st, rowptr, col, val,
                        dinv_out, N, val_out);
